@@ -1,0 +1,104 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of this package.
+// Wave = 64 lanes; every memory-bound kernel moves 16 B per lane per access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DTF_WAVE 64
+
+enum DtfDtype : int { DTF_F32 = 0, DTF_BF16 = 1 };
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) {
+    return __uint_as_float(((unsigned int)u) << 16);
+}
+
+// round-to-nearest-even, NaN stays NaN (quiet).  hipcc folds a pair of these
+// into one v_cvt_pk_bf16_f32 on gfx950 when written as a plain __bf16 cast.
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    f32x2_t v = {lo, hi};
+    bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned int, b);
+}
+
+// 8 consecutive elements -> 8 floats, from either dtype (16-B aligned for bf16,
+// 32-B span for f32 read as two 16-B loads).
+template <int DT>
+__device__ __forceinline__ void load8(const void* base, int64_t i, float (&v)[8]) {
+    if constexpr (DT == DTF_BF16) {
+        u32x4 r = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(base) + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(r[k] << 16);
+            v[2 * k + 1] = __uint_as_float(r[k] & 0xffff0000u);
+        }
+    } else {
+        const f32x4* p = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + i);
+        f32x4 a = p[0], b = p[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ void store8(void* base, int64_t i, const float (&v)[8]) {
+    if constexpr (DT == DTF_BF16) {
+        u32x4 r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(base) + i) = r;
+    } else {
+        f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + i);
+        f32x4 a, b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = v[k]; b[k] = v[4 + k]; }
+        p[0] = a; p[1] = b;
+    }
+}
+
+template <int DT>
+__device__ __forceinline__ float load1(const void* base, int64_t i) {
+    if constexpr (DT == DTF_BF16) return bf16_to_f32(reinterpret_cast<const unsigned short*>(base)[i]);
+    else return reinterpret_cast<const float*>(base)[i];
+}
+
+template <int DT>
+__device__ __forceinline__ void store1(void* base, int64_t i, float v) {
+    if constexpr (DT == DTF_BF16) reinterpret_cast<unsigned short*>(base)[i] = f32_to_bf16(v);
+    else reinterpret_cast<float*>(base)[i] = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// grid sizing for streaming kernels: enough blocks to fill 256 CUs x 8, then
+// grid-stride (cdna_hip_programming.md Guideline 11)
+static inline int dtf_stream_grid(int64_t work_items, int block) {
+    int64_t b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+#define DTF_CHECK_LAUNCH()                                     \
+    do {                                                       \
+        hipError_t e__ = hipGetLastError();                    \
+        if (e__ != hipSuccess) return (int)e__;                \
+    } while (0)

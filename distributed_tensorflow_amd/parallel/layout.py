@@ -1,0 +1,109 @@
+"""Flat variable placement (new layer N2; replaces external X3, TF1's
+``replica_device_setter`` that decides which PS task owns which variable).
+
+TF1 places whole variables round-robin on the ``ps`` tasks.  Here the dense
+variables of a model are laid out in one flat address space cut into
+*buckets* (the unit of one push/pull collective), and every bucket is split
+into ``world`` equal, 16-byte-aligned slices: shard ``r`` (the PS state hosted
+on rank ``r``) is the concatenation of slice ``r`` of every bucket.  A variable
+may straddle two shards; the checkpoint index records that.
+
+Bucket order is reverse registration order, so the bucket holding the last
+layers -- whose gradients backward produces first -- is pushed first, and the
+bucket holding the first layers is pulled last... i.e. lands right before the
+next forward needs it (SURVEY 5.8 "reverse-layer for push").
+
+Sizing for 7 point-to-point xGMI links: a bucket of B bytes puts B/8 on every
+link, and per-link messages should be >= 1-4 MB, hence the 32 MB default.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+ALIGN = 8  # elements: 16 B in bf16, 32 B in fp32 -> every slice start is 16-B aligned
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class ParamSlot:
+    name: str
+    numel: int
+    index: int          # position in the registration-order list
+    bucket: int = -1
+    flat_off: int = -1  # element offset in the flat space
+
+
+@dataclass
+class Bucket:
+    index: int
+    start: int = 0      # element offset of the bucket in the flat space
+    size: int = 0       # elements, multiple of world * ALIGN
+    shard: int = 0      # size // world
+    shard_off: int = 0  # offset of this bucket's slice inside a rank's shard
+    params: list = field(default_factory=list)  # ParamSlot indices, in pack order
+
+
+class FlatLayout:
+    def __init__(self, named_numels, world, bucket_elems):
+        self.world = int(world)
+        self.slots = [ParamSlot(n, int(k), i) for i, (n, k) in enumerate(named_numels)]
+        self.buckets = []
+        cur = Bucket(0)
+        fill = 0
+        for slot in reversed(self.slots):
+            need = _round_up(slot.numel, ALIGN)
+            if fill and fill + need > bucket_elems:
+                self._close(cur, fill)
+                cur = Bucket(len(self.buckets))
+                fill = 0
+            slot.bucket = cur.index
+            slot.flat_off = fill          # relative for now
+            cur.params.append(slot.index)
+            fill += need
+        self._close(cur, fill)
+        start = shard_off = 0
+        for b in self.buckets:
+            b.start, b.shard_off = start, shard_off
+            for i in b.params:
+                self.slots[i].flat_off += start
+            start += b.size
+            shard_off += b.shard
+        self.total = start
+        self.shard_total = shard_off
+
+    def _close(self, b, fill):
+        b.size = _round_up(max(fill, 1), self.world * ALIGN)
+        b.shard = b.size // self.world
+        self.buckets.append(b)
+
+    # -- address translation ------------------------------------------------
+    def shard_range(self, bucket, rank):
+        """Flat-space element range owned by ``rank`` inside ``bucket``."""
+        b = self.buckets[bucket]
+        return b.start + rank * b.shard, b.start + (rank + 1) * b.shard
+
+    def owner_pieces(self, slot_index):
+        """``[(rank, shard_elem_off, param_elem_off, length), ...]`` describing
+        where the elements of a variable live in the ranks' shards."""
+        s = self.slots[slot_index]
+        b = self.buckets[s.bucket]
+        out = []
+        pos, end = s.flat_off, s.flat_off + s.numel
+        while pos < end:
+            rel = pos - b.start
+            rank = rel // b.shard
+            in_slice = rel - rank * b.shard
+            length = min(end - pos, b.shard - in_slice)
+            out.append((rank, b.shard_off + in_slice, pos - s.flat_off, length))
+            pos += length
+        return out
+
+    def describe(self):
+        return {
+            "world": self.world, "total": self.total, "shard_total": self.shard_total,
+            "buckets": [{"start": b.start, "size": b.size, "shard": b.shard, "shard_off": b.shard_off,
+                         "params": [self.slots[i].name for i in b.params]} for b in self.buckets],
+        }

@@ -1,0 +1,145 @@
+"""Task entry point: the ``/notebooks/entry.sh`` of this framework (external X1).
+
+The launcher runs ``python -m distributed_tensorflow_amd.service.entry`` with
+exactly the argv the reference gives its container (``handlers/train_handler.py:82-83``)::
+
+    <job_name> <task_index> <ps_hosts> <worker_hosts> <file> <data> <export> <hdfs_web> <hdfs_namenode>
+
+and turns the TF1 cluster description into a ``torch.distributed`` rendezvous:
+host names are resolved through the launcher's loopback DNS (``DTF_DNS``), rank
+0's Service address becomes ``MASTER_ADDR:MASTER_PORT`` (the reference's
+``tfId:2222``), ranks are ordered PS-first in the dedicated placement and are
+the workers alone in the colocated one.  A colocated ``ps`` task hosts no
+variables: it is the job's never-exiting coordinator process (the thing
+``remove_ps.py`` exists to reap) and does not even import torch.
+"""
+from __future__ import annotations
+
+import json
+import os
+import signal
+import sys
+import time
+
+
+def _resolve(host, dns):
+    name, _, port = host.partition(":")
+    hp = dns.get(name)
+    if hp:
+        a, _, p = hp.partition(":")
+        return a, int(p)
+    return name, int(port or 2222)
+
+
+def _metrics_sink(uid):
+    """hset into ``<uid>:metrics`` if a store is reachable; never fatal."""
+    try:
+        from ..utils.store import RedisHelper
+
+        rc = RedisHelper().getRedis()
+        rc.ping()
+    except Exception:
+        return lambda **kw: None
+
+    def put(**kw):
+        try:
+            for k, v in kw.items():
+                rc.hset(uid + ":metrics", k, repr(v) if isinstance(v, float) else v)
+        except Exception:
+            pass
+
+    return put
+
+
+def ps_join_forever():
+    """``server.join()``: block until killed."""
+    signal.signal(signal.SIGTERM, lambda *a: sys.exit(143))
+    while True:
+        signal.pause()
+
+
+def main(argv=None):
+    t_start = time.time()
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) < 4:
+        print("usage: entry <job_name> <task_index> <ps_hosts> <worker_hosts> [file data export hdfs_web hdfs_nn]",
+              file=sys.stderr)
+        return 2
+    argv += [""] * (9 - len(argv))
+    job_name, task_index, ps_csv, worker_csv, file_field, data_dir, export_dir = argv[:7]
+    task_index = int(task_index)
+    ps_hosts = [h for h in ps_csv.split(",") if h]
+    worker_hosts = [h for h in worker_csv.split(",") if h]
+    dns = json.loads(os.environ.get("DTF_DNS", "{}"))
+    task_name = os.environ.get("DTF_TASK_NAME", "%s-%d" % (job_name, task_index))
+    from ..utils.naming import parse_task_name
+
+    parsed = parse_task_name(task_name)
+    uid = parsed[0] if parsed else os.environ.get("DTF_JOB_UID", "local")
+    print("[entry] %s job=%s index=%d ps=%d workers=%d file=%r export=%r" % (
+        task_name, job_name, task_index, len(ps_hosts), len(worker_hosts), file_field, export_dir), flush=True)
+
+    from ..train.jobspec import parse_file_field
+
+    try:
+        kind, spec = parse_file_field(file_field)
+    except ValueError as e:
+        print("[entry] %s" % e, file=sys.stderr, flush=True)
+        return 2
+
+    os.environ.update({
+        "DTF_JOB_NAME": job_name, "DTF_TASK_INDEX": str(task_index), "DTF_JOB_UID": uid,
+        "DTF_PS_HOSTS": ps_csv, "DTF_WORKER_HOSTS": worker_csv,
+    })
+
+    if kind == "script":
+        # user script: give it a worker-only rendezvous and run it
+        if job_name == "ps":
+            ps_join_forever()
+        addr, port = _resolve(worker_hosts[0], dns)
+        os.environ.update({"RANK": str(task_index), "WORLD_SIZE": str(len(worker_hosts)),
+                           "LOCAL_RANK": "0", "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
+        import runpy
+
+        sys.argv = [spec] + argv
+        runpy.run_path(spec, run_name="__main__")
+        return 0
+
+    opts = spec
+    num_gpus = int(os.environ.get("DTF_NUM_GPUS", "0"))
+    placement = opts.placement
+    if placement == "auto":
+        placement = "colocated" if (num_gpus > 0 or not ps_hosts) else "dedicated"
+    if opts.update_mode == "async" and placement == "colocated":
+        opts.update_mode = "stale"      # collective counterpart of the async update
+    P, W = len(ps_hosts), len(worker_hosts)
+
+    if placement == "colocated":
+        if job_name == "ps":
+            print("[entry] colocated placement: ps task is the job coordinator; joining forever", flush=True)
+            ps_join_forever()
+        rank, world = task_index, W
+        addr, port = _resolve(worker_hosts[0], dns)
+    else:
+        if P < 1:
+            print("[entry] dedicated placement needs at least one ps task", file=sys.stderr)
+            return 2
+        rank = task_index if job_name == "ps" else P + task_index
+        world = P + W
+        addr, port = _resolve(ps_hosts[0], dns)
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0",
+                       "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
+
+    put = _metrics_sink(uid)
+    from ..train.trainer import run_task
+
+    rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,
+                  opts=opts, data_dir=data_dir, export_dir=export_dir, metrics=put, t_start=t_start)
+    if job_name == "ps":
+        print("[entry] ps task finished serving; joining forever (waiting to be reaped)", flush=True)
+        ps_join_forever()
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main() or 0)

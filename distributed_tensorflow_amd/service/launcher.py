@@ -1,0 +1,526 @@
+"""Single-node launcher: the Kubernetes replacement (new layer N4, externals X1/X7).
+
+The reference hands its manifests to a kube-apiserver through the python
+``kubernetes`` client (``CoreV1Api.create_namespaced_service`` /
+``BatchV1Api.create_namespaced_job`` ``handlers/train_handler.py:52,112``;
+``delete_namespaced_job/service`` ``service/remove_ps.py:31-33,49``; watch stream
+``service/tf_cleaner.py:40``).  :class:`LocalCluster` exposes those same calls on
+one node:
+
+* a *Service* becomes an entry in a loopback "cluster DNS" (``tfId:2222`` ->
+  ``127.0.0.1:<port>``) that task processes receive through ``DTF_DNS``;
+* a *Job* becomes one OS process (the container "image" is a python module,
+  the container command is forwarded unchanged as argv) pinned to the
+  ``amd.com/gpu`` devices it requested through ``HIP_VISIBLE_DEVICES``; a Job
+  that does not fit stays Pending until devices are released, like an
+  unschedulable pod;
+* the Job controller's status reporting becomes ADDED / MODIFIED / DELETED
+  events with ``status.active/succeeded/failed``, replayable from a
+  ``resourceVersion`` (the reference's watch has no resume);
+* Foreground delete becomes SIGTERM -> grace -> SIGKILL on the task's process
+  group (ranks blocked in an RCCL collective ignore SIGTERM) followed by an
+  HBM-reclaim check of the devices the task held.
+"""
+from __future__ import annotations
+
+import copy
+import glob
+import json
+import logging
+import os
+import signal
+import subprocess
+import sys
+import threading
+import time
+
+from ..utils.config import ApiConfig
+
+log = logging.getLogger(__name__)
+
+
+class ApiException(Exception):
+    def __init__(self, status=500, reason=""):
+        super().__init__("(%s) %s" % (status, reason))
+        self.status, self.reason = status, reason
+
+
+class AttrDict(dict):
+    """dict with attribute access, so both ``obj["metadata"]["name"]`` and the
+    reference's ``event['object'].metadata.name`` / ``status.succeeded`` work."""
+
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError:
+            return None
+        return v
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    @staticmethod
+    def wrap(o):
+        if isinstance(o, dict):
+            return AttrDict({k: AttrDict.wrap(v) for k, v in o.items()})
+        if isinstance(o, list):
+            return [AttrDict.wrap(v) for v in o]
+        return o
+
+
+# ---------------------------------------------------------------------------
+# HBM accounting without touching HIP in the service process
+# ---------------------------------------------------------------------------
+
+def hbm_used_bytes():
+    """Per-device used VRAM from sysfs (``mem_info_vram_used``), index order =
+    DRM card order.  Empty list when no amdgpu device is visible (CPU box)."""
+    out = []
+    cards = []
+    for p in glob.glob("/sys/class/drm/card[0-9]*/device/mem_info_vram_used"):
+        try:
+            idx = int(p.split("/card")[1].split("/")[0])
+        except ValueError:
+            continue
+        cards.append((idx, p))
+    for _, p in sorted(cards):
+        try:
+            with open(p) as f:
+                out.append(int(f.read().strip()))
+        except (OSError, ValueError):
+            out.append(-1)
+    return out
+
+
+def visible_gpu_count(default=0):
+    n = len(hbm_used_bytes())
+    return n if n else default
+
+
+class _Task:
+    def __init__(self, name, namespace, body):
+        self.name, self.namespace, self.body = name, namespace, body
+        self.proc = None
+        self.gpus = []
+        self.requested_gpus = 0
+        self.status = {"active": 0, "succeeded": None, "failed": None,
+                       "startTime": None, "completionTime": None, "phase": "Pending"}
+        self.deleted = False
+        self.log_path = None
+        self.exit_code = None
+        self.hbm_before = None
+
+
+class LocalCluster:
+    def __init__(self, gpus=None, log_dir=None, python=None, extra_env=None, cfg=None):
+        cfg = cfg or ApiConfig()
+        self._cfg = cfg
+        if gpus is None:
+            n = visible_gpu_count(0)
+            cap = cfg.getint("launcher", "gpus_per_node", 8)
+            gpus = list(range(min(n, cap))) if n else []
+        self._free_gpus = list(gpus)
+        self._all_gpus = list(gpus)
+        self._log_dir = log_dir or cfg.get("launcher", "log_dir", "logs/tasks")
+        self._python = python or sys.executable
+        self._extra_env = dict(extra_env or {})
+        self._grace = cfg.getfloat("launcher", "grace_seconds", 5)
+        self._kill_wait = cfg.getfloat("launcher", "kill_seconds", 5)
+        self._port_next = cfg.getint("launcher", "port_base", 23000)
+        self._lock = threading.RLock()
+        self._cv = threading.Condition(self._lock)
+        self._services = {}   # (ns, name) -> body(with status.hostPort)
+        self._jobs = {}       # (ns, name) -> _Task
+        self._events = []     # (rv, type, snapshot)
+        self._rv = 0
+        self._closed = False
+        self.reclaim_reports = []   # one dict per reaped GPU task
+
+    # ------------------------------------------------------------------ DNS
+    def _alloc_port(self):
+        import socket
+
+        for _ in range(2000):
+            port = self._port_next
+            self._port_next += 1
+            if self._port_next > 60000:
+                self._port_next = self._cfg.getint("launcher", "port_base", 23000)
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+                try:
+                    s.bind(("127.0.0.1", port))
+                    return port
+                except OSError:
+                    continue
+        raise ApiException(507, "no free loopback port for service")
+
+    def resolve(self, name, namespace=None):
+        with self._lock:
+            for (ns, n), body in self._services.items():
+                if n == name and (namespace is None or ns == namespace):
+                    return body["status"]["hostPort"]
+        return None
+
+    def dns_map(self, uid=None):
+        with self._lock:
+            return {n: b["status"]["hostPort"] for (_, n), b in self._services.items()
+                    if uid is None or ("-" + str(uid) + "-") in n}
+
+    # ------------------------------------------------------------- services
+    def create_namespaced_service(self, namespace, body):
+        name = body["metadata"]["name"]
+        with self._lock:
+            if (namespace, name) in self._services:
+                raise ApiException(409, "service %s already exists" % name)
+            b = copy.deepcopy(body)
+            b.setdefault("metadata", {})["namespace"] = namespace
+            b["status"] = {"hostPort": "127.0.0.1:%d" % self._alloc_port()}
+            self._services[(namespace, name)] = b
+            return AttrDict.wrap(b)
+
+    def delete_namespaced_service(self, name, namespace, body=None):
+        with self._lock:
+            b = self._services.pop((namespace, name), None)
+        if b is None:
+            raise ApiException(404, "service %s not found" % name)
+        return AttrDict.wrap({"status": "Success", "details": {"name": name, "kind": "services"}})
+
+    def list_namespaced_service(self, namespace):
+        with self._lock:
+            return AttrDict.wrap({"items": [copy.deepcopy(b) for (ns, _), b in self._services.items()
+                                            if ns == namespace]})
+
+    # ----------------------------------------------------------------- jobs
+    def _snapshot(self, t):
+        b = copy.deepcopy(t.body)
+        b.setdefault("metadata", {})["namespace"] = t.namespace
+        b["status"] = dict(t.status)
+        b["status"]["gpus"] = list(t.gpus)
+        b["status"]["exitCode"] = t.exit_code
+        b["status"]["logPath"] = t.log_path
+        return b
+
+    def _emit(self, typ, t):
+        # caller holds the lock
+        self._rv += 1
+        snap = self._snapshot(t)
+        snap["metadata"]["resourceVersion"] = str(self._rv)
+        self._events.append((self._rv, typ, snap))
+        self._cv.notify_all()
+
+    @staticmethod
+    def _gpu_request(body, resource_name):
+        n = 0
+        for c in body["spec"]["template"]["spec"]["containers"]:
+            n += int(((c.get("resources") or {}).get("limits") or {}).get(resource_name, 0))
+        return n
+
+    def create_namespaced_job(self, namespace, body):
+        name = body["metadata"]["name"]
+        with self._lock:
+            if self._closed:
+                raise ApiException(503, "cluster is shut down")
+            if (namespace, name) in self._jobs:
+                raise ApiException(409, "job %s already exists" % name)
+            t = _Task(name, namespace, copy.deepcopy(body))
+            t.requested_gpus = self._gpu_request(body, self._cfg.get("launcher", "gpu_resource", "amd.com/gpu"))
+            if t.requested_gpus > len(self._all_gpus) and self._all_gpus:
+                raise ApiException(422, "job %s requests %d %s, node has %d" % (
+                    name, t.requested_gpus, "amd.com/gpu", len(self._all_gpus)))
+            self._jobs[(namespace, name)] = t
+            self._emit("ADDED", t)
+            self._schedule()
+            return AttrDict.wrap(self._snapshot(t))
+
+    def _schedule(self):
+        # caller holds the lock; start every pending task that fits (FIFO)
+        for t in list(self._jobs.values()):
+            if t.proc is not None or t.deleted or t.status["phase"] != "Pending":
+                continue
+            need = t.requested_gpus if self._all_gpus else 0
+            if need > len(self._free_gpus):
+                continue
+            t.gpus = [self._free_gpus.pop(0) for _ in range(need)]
+            try:
+                self._start(t)
+            except Exception as e:  # spawn failure = failed job, not a dead service
+                log.exception("failed to start %s", t.name)
+                self._free_gpus.extend(t.gpus)
+                t.gpus = []
+                t.status.update(active=0, failed=1, phase="Failed", completionTime=time.time())
+                t.exit_code = -1
+                t.status["message"] = str(e)
+                self._emit("MODIFIED", t)
+
+    def _start(self, t):
+        c = t.body["spec"]["template"]["spec"]["containers"][0]
+        image = c.get("image") or self._cfg.get("image", "tensorflow")
+        argv = list(c.get("command") or [])
+        # the container entrypoint path is symbolic: argv[1:] is the contract
+        args = argv[1:] if argv and argv[0].endswith("entry.sh") else argv
+        cmd = [self._python, "-u", "-m", image] + [str(a) for a in args]
+        env = dict(os.environ)
+        env.update(self._extra_env)
+        uid = t.name.split("-ps-")[0].split("-worker-")[0][3:]
+        env["DTF_TASK_NAME"] = t.name
+        env["DTF_DNS"] = json.dumps(self.dns_map(uid))
+        env["DTF_NUM_GPUS"] = str(len(t.gpus))
+        if t.gpus:
+            env["HIP_VISIBLE_DEVICES"] = ",".join(str(g) for g in t.gpus)
+        elif self._all_gpus:
+            env["HIP_VISIBLE_DEVICES"] = ""    # host-side task: no device
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        os.makedirs(self._log_dir, exist_ok=True)
+        t.log_path = os.path.join(self._log_dir, t.name + ".log")
+        used = hbm_used_bytes()
+        t.hbm_before = {g: used[g] for g in t.gpus if g < len(used)}
+        logf = open(t.log_path, "ab", buffering=0)
+        try:
+            t.proc = subprocess.Popen(cmd, env=env, stdout=logf, stderr=subprocess.STDOUT,
+                                      stdin=subprocess.DEVNULL, start_new_session=True)
+        finally:
+            logf.close()
+        t.status.update(active=1, phase="Running", startTime=time.time())
+        self._emit("MODIFIED", t)
+        threading.Thread(target=self._reap, args=(t,), name="wait-" + t.name, daemon=True).start()
+
+    def _reap(self, t):
+        rc = t.proc.wait()
+        with self._lock:
+            t.exit_code = rc
+            self._release_gpus(t)
+            if t.deleted:
+                return
+            if rc == 0:
+                t.status.update(active=0, succeeded=1, phase="Succeeded", completionTime=time.time())
+            else:
+                t.status.update(active=0, failed=1, phase="Failed", completionTime=time.time())
+            self._emit("MODIFIED", t)
+            self._schedule()
+
+    def _release_gpus(self, t):
+        for g in t.gpus:
+            if g not in self._free_gpus:
+                self._free_gpus.append(g)
+        self._free_gpus.sort()
+
+    def read_namespaced_job(self, name, namespace):
+        with self._lock:
+            t = self._jobs.get((namespace, name))
+            if t is None:
+                raise ApiException(404, "job %s not found" % name)
+            return AttrDict.wrap(self._snapshot(t))
+
+    def list_namespaced_job(self, namespace):
+        with self._lock:
+            return AttrDict.wrap({
+                "metadata": {"resourceVersion": str(self._rv)},
+                "items": [self._snapshot(t) for (ns, _), t in self._jobs.items() if ns == namespace],
+            })
+
+    def _kill(self, t):
+        """SIGTERM -> grace -> SIGKILL on the task's process group."""
+        p = t.proc
+        if p is None or p.poll() is not None:
+            return "exited"
+        how = "SIGTERM"
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            p.wait(self._grace)
+        except subprocess.TimeoutExpired:
+            how = "SIGKILL"
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            try:
+                p.wait(self._kill_wait)
+            except subprocess.TimeoutExpired:
+                how = "unkillable"
+        return how
+
+    def _verify_reclaim(self, t):
+        if not t.hbm_before:
+            return None
+        slack = self._cfg.getint("launcher", "hbm_reclaim_slack_mb", 64) << 20
+        deadline = time.time() + 5.0
+        while True:
+            used = hbm_used_bytes()
+            after = {g: used[g] for g in t.hbm_before if g < len(used)}
+            ok = all(after[g] <= t.hbm_before[g] + slack for g in after)
+            if ok or time.time() > deadline:
+                break
+            time.sleep(0.1)
+        rep = {"task": t.name, "gpus": list(t.hbm_before), "before": t.hbm_before, "after": after,
+               "reclaimed": ok}
+        self.reclaim_reports.append(rep)
+        log.info("HBM reclaim %s", rep)
+        return rep
+
+    def delete_namespaced_job(self, name, namespace, body=None):
+        with self._lock:
+            t = self._jobs.get((namespace, name))
+            if t is None:
+                raise ApiException(404, "job %s not found" % name)
+            t.deleted = True
+        how = self._kill(t)
+        rep = self._verify_reclaim(t)
+        with self._lock:
+            self._jobs.pop((namespace, name), None)
+            self._release_gpus(t)
+            t.status.update(active=0, phase="Deleted")
+            self._emit("DELETED", t)
+            self._schedule()
+        return AttrDict.wrap({"status": "Success",
+                              "details": {"name": name, "kind": "jobs", "signal": how, "hbm": rep}})
+
+    # ---------------------------------------------------------------- watch
+    def watch(self, namespace, resource_version=0, timeout=None, stop=None):
+        """Generator of ``{"type","object"}`` events newer than
+        ``resource_version`` (0 = replay everything, like a fresh k8s watch
+        replays ADDED for existing objects).  ``timeout=None`` blocks forever
+        (the reference's ``timeout_seconds=0``)."""
+        rv = int(resource_version)
+        deadline = None if timeout is None else time.monotonic() + timeout
+        idx = 0
+        while True:
+            batch = []
+            with self._cv:
+                while idx < len(self._events) and self._events[idx][0] <= rv:
+                    idx += 1
+                if idx >= len(self._events):
+                    if self._closed or (stop is not None and stop.is_set()):
+                        return
+                    left = 0.25 if deadline is None else min(0.25, deadline - time.monotonic())
+                    if left <= 0:
+                        return
+                    self._cv.wait(left)
+                batch = self._events[idx:]
+                idx = len(self._events)
+            for erv, typ, snap in batch:
+                if snap["metadata"].get("namespace") != namespace:
+                    continue
+                rv = erv
+                yield {"type": typ, "object": AttrDict.wrap(copy.deepcopy(snap))}
+
+    def events_since(self, namespace, resource_version=0, wait=0.0):
+        """Non-generator form used by the HTTP API (long poll)."""
+        rv = int(resource_version)
+        deadline = time.monotonic() + wait
+        with self._cv:
+            while True:
+                out = [{"type": typ, "object": snap} for erv, typ, snap in self._events
+                       if erv > rv and snap["metadata"].get("namespace") == namespace]
+                left = deadline - time.monotonic()
+                if out or left <= 0 or self._closed:
+                    return out, self._rv
+                self._cv.wait(min(left, 0.25))
+
+    # ------------------------------------------------------------- shutdown
+    def shutdown(self):
+        with self._lock:
+            self._closed = True
+            tasks = list(self._jobs.values())
+            self._cv.notify_all()
+        for t in tasks:
+            t.deleted = True
+            self._kill(t)
+
+    def free_gpus(self):
+        with self._lock:
+            return list(self._free_gpus)
+
+
+# ---------------------------------------------------------------------------
+# Process-wide default cluster + HTTP client with the same surface
+# ---------------------------------------------------------------------------
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def install_cluster(cluster):
+    global _default
+    _default = cluster
+
+
+def get_cluster():
+    """The in-process :class:`LocalCluster` if one is installed (all-in-one
+    service), else an HTTP :class:`ClusterClient` to ``[service] host:port``
+    (the watcher / reaper daemons run as separate processes like the
+    reference's ``tf_cleaner.py`` / ``remove_ps.py``)."""
+    global _default
+    with _default_lock:
+        if _default is None:
+            cfg = ApiConfig()
+            _default = ClusterClient("http://%s:%d" % (cfg.get("service", "host", "127.0.0.1"),
+                                                       cfg.getint("service", "port")))
+        return _default
+
+
+class ClusterClient:
+    """k8s-shaped REST client for the node agent served by ``service/api.py``."""
+
+    def __init__(self, base_url, timeout=30.0):
+        self._base = base_url.rstrip("/")
+        self._timeout = timeout
+
+    def _req(self, method, path, body=None, timeout=None):
+        import urllib.error
+        import urllib.request
+
+        data = None if body is None else json.dumps(body).encode()
+        req = urllib.request.Request(self._base + path, data=data, method=method,
+                                     headers={"Content-Type": "application/json"})
+        try:
+            with urllib.request.urlopen(req, timeout=timeout or self._timeout) as r:
+                return json.loads(r.read().decode() or "null")
+        except urllib.error.HTTPError as e:
+            raise ApiException(e.code, e.read().decode(errors="replace"))
+        except urllib.error.URLError as e:
+            raise ApiException(503, str(e.reason))
+
+    def create_namespaced_service(self, namespace, body):
+        return AttrDict.wrap(self._req("POST", "/api/v1/namespaces/%s/services" % namespace, body))
+
+    def delete_namespaced_service(self, name, namespace, body=None):
+        return AttrDict.wrap(self._req("DELETE", "/api/v1/namespaces/%s/services/%s" % (namespace, name)))
+
+    def create_namespaced_job(self, namespace, body):
+        return AttrDict.wrap(self._req("POST", "/apis/batch/v1/namespaces/%s/jobs" % namespace, body))
+
+    def delete_namespaced_job(self, name, namespace, body=None):
+        return AttrDict.wrap(self._req("DELETE", "/apis/batch/v1/namespaces/%s/jobs/%s" % (namespace, name),
+                                       timeout=120))
+
+    def read_namespaced_job(self, name, namespace):
+        return AttrDict.wrap(self._req("GET", "/apis/batch/v1/namespaces/%s/jobs/%s" % (namespace, name)))
+
+    def list_namespaced_job(self, namespace):
+        return AttrDict.wrap(self._req("GET", "/apis/batch/v1/namespaces/%s/jobs" % namespace))
+
+    def watch(self, namespace, resource_version=0, timeout=None, stop=None):
+        """Long-poll watch with resourceVersion resume and reconnect (both are
+        missing from the reference's watch loop)."""
+        rv = int(resource_version)
+        deadline = None if timeout is None else time.monotonic() + timeout
+        backoff = 0.1
+        while stop is None or not stop.is_set():
+            if deadline is not None and time.monotonic() >= deadline:
+                return
+            try:
+                r = self._req("GET", "/apis/batch/v1/namespaces/%s/jobs?watch=1&resourceVersion=%d&wait=1"
+                              % (namespace, rv), timeout=15)
+                backoff = 0.1
+            except ApiException as e:
+                log.warning("watch reconnect after error: %s", e)
+                time.sleep(backoff)
+                backoff = min(backoff * 2, 2.0)
+                continue
+            for ev in r["events"]:
+                rv = max(rv, int(ev["object"]["metadata"]["resourceVersion"]))
+                yield {"type": ev["type"], "object": AttrDict.wrap(ev["object"])}

@@ -1,0 +1,89 @@
+"""Interpretation of the job spec's ``file`` / ``data`` / ``export`` fields.
+
+The reference forwards them verbatim to ``/notebooks/entry.sh`` as argv[5..7]
+(``handlers/train_handler.py:82-83``) where a script inside the opaque image
+fetches ``file`` from HDFS and runs it.  Here ``file`` is either
+
+* a built-in workload: ``resnet50`` or ``builtin://resnet50?steps=200&batch=256``
+  (query keys override the ``[train]`` config section), or
+* a path to a user python script, run with the cluster description in the
+  environment (``DTF_JOB_NAME``, ``DTF_TASK_INDEX``, ``DTF_PS_HOSTS``,
+  ``DTF_WORKER_HOSTS``, ``RANK``/``WORLD_SIZE``/``MASTER_ADDR``/``MASTER_PORT``)
+  and the same nine arguments in ``sys.argv``.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from urllib.parse import parse_qsl, urlparse
+
+from ..models import model_names
+from ..utils.config import ApiConfig
+
+
+@dataclass
+class TrainOptions:
+    model: str = "mnist_mlp"
+    steps: int = 100
+    batch: int = 64                 # per worker
+    update_mode: str = "sync"       # sync | stale | async
+    placement: str = "auto"         # auto | colocated | dedicated
+    bucket_mb: float = 32.0
+    wire_dtype: str = "auto"        # auto | bf16 | fp32
+    push: str = "reduce_scatter"    # reduce_scatter | all_to_all
+    lr: float = -1.0                # <0: model default
+    optimizer: str = ""             # "": model default
+    ckpt_every: int = 0             # 0: only at the end (when export is set)
+    resume: bool = False
+    seed: int = 1234
+    log_every: int = 10
+    fault: str = ""                 # e.g. "exit:worker=1,step=3,code=17" / "hang:worker=0,step=2"
+    graph: bool = False
+    extra: dict = field(default_factory=dict)
+
+
+_INT = {"steps", "batch", "ckpt_every", "seed", "log_every"}
+_FLOAT = {"bucket_mb", "lr"}
+_BOOL = {"resume", "graph"}
+
+
+def _coerce(key, val):
+    if key in _INT:
+        return int(val)
+    if key in _FLOAT:
+        return float(val)
+    if key in _BOOL:
+        return str(val).lower() in ("1", "true", "yes", "on")
+    return val
+
+
+def parse_file_field(file_field, cfg=None):
+    """-> ``("builtin", TrainOptions)`` or ``("script", path)``; raises
+    ``ValueError`` for something that is neither."""
+    cfg = cfg or ApiConfig()
+    opts = TrainOptions()
+    for key in ("steps", "bucket_mb", "update_mode", "placement", "wire_dtype"):
+        if cfg.has_option("train", key):
+            setattr(opts, key, _coerce(key, cfg.get("train", key)))
+    f = (file_field or "").strip()
+    u = urlparse(f)
+    name = None
+    if u.scheme == "builtin":
+        name = (u.netloc + u.path).strip("/")
+    elif u.scheme in ("", "file") and not os.path.exists(u.path):
+        cand = u.path.strip("/").split("?")[0]
+        if cand.lower().replace("-", "_") in model_names():
+            name = cand
+    if name is not None:
+        opts.model = name.lower().replace("-", "_")
+        for k, v in parse_qsl(u.query):
+            if hasattr(opts, k) and k != "extra":
+                setattr(opts, k, _coerce(k, v))
+            else:
+                opts.extra[k] = v
+        return "builtin", opts
+    path = u.path if u.scheme in ("", "file") else f
+    if os.path.isfile(path):
+        return "script", path
+    raise ValueError("job 'file' %r is neither a built-in model (%s) nor an existing script"
+                     % (file_field, ", ".join(model_names())))

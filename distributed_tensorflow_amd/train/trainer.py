@@ -1,0 +1,208 @@
+"""Worker / PS task bodies (new layer N3): what the user's TF1 script does inside
+the reference's ``tf-dis`` image (external E0) -- build the model,
+join the cluster, and loop ``pull -> forward/backward -> push -> apply``.
+
+``run_task`` is called by ``service/entry.py`` in every task process of a job;
+``train_loop`` is the reusable loop (also used by ``bench.py``).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import torch
+
+from ..models import get_model_module
+from ..parallel import checkpoint as ckpt
+from ..parallel.comm import Comm
+from ..parallel.ps_runtime import OptimizerSpec, ShardedPS
+
+
+def _wire_dtype(opts, device):
+    if opts.wire_dtype in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    if opts.wire_dtype in ("fp32", "float32"):
+        return torch.float32
+    return torch.bfloat16 if device.type == "cuda" else torch.float32
+
+
+def _optimizer(mod, opts):
+    spec = mod.default_optimizer() if hasattr(mod, "default_optimizer") else OptimizerSpec()
+    if opts.optimizer:
+        spec.kind = opts.optimizer
+    if opts.lr > 0:
+        spec.lr = opts.lr
+    return spec
+
+
+def _parse_fault(s):
+    """``"exit:worker=1,step=3,code=17"`` -> dict (fault injection)."""
+    if not s:
+        return None
+    kind, _, rest = s.partition(":")
+    d = {"kind": kind, "worker": 0, "step": 1, "code": 17}
+    for kv in rest.split(","):
+        if "=" in kv:
+            k, v = kv.split("=", 1)
+            d[k] = int(v)
+    return d
+
+
+def _inject(fault, worker, step):
+    if fault and fault["worker"] == worker and fault["step"] == step:
+        print("[fault] injecting %s at worker %d step %d" % (fault["kind"], worker, step), flush=True)
+        if fault["kind"] == "exit":
+            os._exit(fault["code"])
+        if fault["kind"] == "hang":
+            while True:
+                time.sleep(3600)
+        if fault["kind"] == "raise":
+            raise RuntimeError("injected fault")
+
+
+def prepare_model(mod, opts, device):
+    kw = dict(opts.extra)
+    model = mod.build(**kw)
+    if hasattr(mod, "prepare"):
+        model = mod.prepare(model, device)
+    else:
+        model = model.to(device)
+    return model
+
+
+def replicated_state(model, ps):
+    rep = {"global_step": torch.tensor(ps.global_step, dtype=torch.int64)}
+    for n, b in model.named_buffers():
+        rep[n] = b
+    return rep
+
+
+def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=None, on_step=None,
+               items_per_step=None, start_step=0):
+    """Runs ``steps`` PS steps; returns (last_loss, seconds, steps_done)."""
+    dev = ps.device
+    t0 = time.time()
+    last = None
+    loss = None
+    for it in range(start_step, start_step + steps):
+        _inject(fault, worker, it + 1)
+        loss = mod.loss_fn(model, batch)
+        loss.backward()
+        ps.step()
+        if on_step is not None:
+            on_step(it + 1, loss)
+        if log_every and (it + 1) % log_every == 0:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            now = time.time()
+            last = float(loss.detach().float().item())
+            rate = (it + 1 - start_step) * (items_per_step or 0) / max(now - t0, 1e-9)
+            print("[train] step %d loss %.5f  %.1f items/s" % (it + 1, last, rate), flush=True)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    if loss is not None:
+        last = float(loss.detach().float().item())
+    return last, time.time() - t0, steps
+
+
+def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_dir, export_dir, metrics,
+             t_start=None):
+    t_start = t_start or time.time()
+    mod = get_model_module(opts.model)
+    use_cuda = torch.cuda.is_available() and int(os.environ.get("DTF_NUM_GPUS", "1")) > 0
+    device = torch.device("cuda", 0) if use_cuda else torch.device("cpu")
+    torch.manual_seed(opts.seed)
+    comm = Comm.from_env(device)
+    chief = job_name == "worker" and task_index == 0
+    if chief:
+        metrics(t_comm_ready=time.time())
+    wire = _wire_dtype(opts, device)
+    opt = _optimizer(mod, opts)
+    export = export_dir if export_dir and export_dir not in ("/tmp", "") else (export_dir or "")
+    do_ckpt = bool(export_dir) and export_dir != "/tmp"
+
+    # ---------------------------------------------------------------- PS task
+    if placement == "dedicated" and job_name == "ps":
+        from ..parallel.dedicated_ps import PSServer
+
+        with torch.device("meta"):
+            meta_model = mod.build(**opts.extra)
+        shapes = [(n, p.numel()) for n, p in meta_model.named_parameters() if p.requires_grad]
+        srv = PSServer(shapes, comm, num_ps, opt, opts.bucket_mb, wire, device,
+                       "async" if opts.update_mode in ("async", "stale") else "sync")
+        print("[ps %d] serving shard of %d elements (%s)" % (task_index, srv.layout.shard_total,
+                                                             srv.update_mode), flush=True)
+        steps = srv.serve()
+        print("[ps %d] all workers done after %d applies" % (task_index, steps), flush=True)
+        if do_ckpt:
+            sec = {"": srv.master}
+            names = opt.slots
+            if names:
+                sec[names[0]] = srv.slot_m
+            if len(names) > 1:
+                sec[names[1]] = srv.slot_v
+            ckpt.write_shard(export, opts.steps, task_index, num_ps, sec)
+            print("[ps %d] wrote checkpoint shard" % task_index, flush=True)
+        return 0
+
+    # ------------------------------------------------------------ worker task
+    model = prepare_model(mod, opts, device)
+    named = list(model.named_parameters())
+    if placement == "dedicated":
+        from ..parallel.dedicated_ps import PSWorkerClient
+
+        ps = PSWorkerClient(named, comm, num_ps, opt, opts.bucket_mb, wire,
+                            "async" if opts.update_mode in ("async", "stale") else "sync")
+        ps.device = device
+    else:
+        ps = ShardedPS(named, comm, opt, opts.bucket_mb, wire,
+                       "stale" if opts.update_mode in ("async", "stale") else "sync", opts.push)
+    tf_names = mod.tf_variable_names(model) if hasattr(mod, "tf_variable_names") else {}
+    start_step = 0
+    if opts.resume and do_ckpt and placement != "dedicated" and ckpt.latest_step(export) is not None:
+        rd = ckpt.restore_ps(ps, export, tf_names=tf_names)
+        rep = rd.replicated()
+        with torch.no_grad():
+            for n, b in model.named_buffers():
+                if n in rep:
+                    b.copy_(rep[n])
+        start_step = rd.step
+        print("[worker %d] resumed from step %d" % (task_index, start_step), flush=True)
+    batch = mod.synthetic_batch(opts.batch, device=device, seed=opts.seed + 1 + task_index,
+                                **{k: v for k, v in opts.extra.items() if k in ("seq_len",)})
+    fault = _parse_fault(opts.fault)
+    first = {"done": False}
+
+    def on_step(step, loss):
+        if not first["done"]:
+            first["done"] = True
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+            if chief:
+                now = time.time()
+                metrics(t_step1=now, first_loss=float(loss.detach().float().item()))
+                print("[worker 0] first step done %.3f s after task start" % (now - t_start), flush=True)
+        if opts.ckpt_every and do_ckpt and step % opts.ckpt_every == 0 and placement != "dedicated":
+            ckpt.save_ps(ps, export, step, tf_names, replicated_state(model, ps) if chief else None)
+
+    remaining = max(0, opts.steps - start_step)
+    items = opts.batch * num_workers
+    last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
+                               fault=fault, on_step=on_step, items_per_step=items, start_step=start_step)
+    rate = n * items / max(secs, 1e-9)
+    print("[worker %d] done: %d steps in %.2f s, %.1f items/s, final loss %s" % (
+        task_index, n, secs, rate, last), flush=True)
+    if placement == "dedicated":
+        ps.finish()
+        if do_ckpt and chief:
+            shapes = {nm: tuple(p.shape) for nm, p in ps.named_params}
+            variables = ckpt.dense_variable_index(ps.layout, tf_names, shapes, opt.slots)
+            ckpt.write_index(export, opts.steps, num_ps, variables, extra={"optimizer": opt.kind})
+    elif do_ckpt:
+        ckpt.save_ps(ps, export, ps.global_step, tf_names, replicated_state(model, ps) if chief else None)
+    if chief:
+        metrics(t_done=time.time(), step=ps.global_step, items_per_sec=rate,
+                final_loss=last if last is not None else "nan")
+    comm.barrier() if placement != "dedicated" else None
+    return 0

@@ -1,0 +1,44 @@
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "slow: multi-process / end-to-end tests")
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture
+def port():
+    return free_port()
+
+
+@pytest.fixture
+def store():
+    from distributed_tensorflow_amd.utils.store import MemoryStore, RedisHelper
+
+    st = MemoryStore()
+    RedisHelper.install(st)
+    yield st
+    RedisHelper.reset()
+
+
+@pytest.fixture(autouse=True)
+def _clean_config():
+    from distributed_tensorflow_amd.utils.config import ApiConfig
+
+    yield
+    ApiConfig.clear_overrides()

@@ -1,0 +1,83 @@
+"""Config #1 end to end: POST -> spawn -> MNIST MLP with
+1 PS + 2 workers on CPU over gloo -> workers exit 0 -> PS reaped -> store clean."""
+import json
+import os
+import time
+import urllib.request
+
+import pytest
+
+from distributed_tensorflow_amd.parallel.checkpoint import CheckpointReader
+from distributed_tensorflow_amd.service.disTf import AllInOne
+from distributed_tensorflow_amd.utils.config import ApiConfig
+from distributed_tensorflow_amd.utils.naming import parse_task_name
+
+pytestmark = pytest.mark.slow
+
+
+def _post(port, body):
+    req = urllib.request.Request("http://127.0.0.1:%d/v1/train" % port, data=json.dumps(body).encode(), method="POST")
+    with urllib.request.urlopen(req, timeout=30) as r:
+        return json.loads(r.read().decode())
+
+
+def _wait_final(a, uid, timeout=180):
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        rec = json.loads(a.store.get(uid))
+        if "t_cleaned" in rec:
+            return rec
+        time.sleep(0.2)
+    raise AssertionError("job did not finish: %s\n%s" % (a.store.get(uid), _logs(a)))
+
+
+def _logs(a):
+    out = []
+    d = a.cluster._log_dir
+    for f in sorted(os.listdir(d)) if os.path.isdir(d) else []:
+        with open(os.path.join(d, f), errors="replace") as fh:
+            out.append("==== %s\n%s" % (f, fh.read()[-3000:]))
+    return "\n".join(out)
+
+
+@pytest.fixture
+def aio(tmp_path):
+    ApiConfig.override("launcher", "grace_seconds", "1")
+    a = AllInOne(gpus=[], log_dir=str(tmp_path / "tasks"))
+    port = a.start(port=0)
+    yield a, port, tmp_path
+    a.stop()
+
+
+@pytest.mark.parametrize("mode", ["sync", "async"])
+def test_mnist_1ps_2workers_dedicated(aio, mode):
+    a, port, tmp = aio
+    export = str(tmp / ("export-" + mode))
+    names = _post(port, {"type": "tensorflow", "export": export,
+                         "file": "builtin://mnist_mlp?steps=30&batch=64&update_mode=%s&log_every=10" % mode,
+                         "detail": {"ps": 1, "worker": 2}})
+    uid = parse_task_name(names[0])[0]
+    rec = _wait_final(a, uid)
+    assert rec["status"] == "succeeded", _logs(a)
+    m = a.store.hgetall(uid + ":metrics")
+    assert float(m["final_loss"]) < float(m["first_loss"]) * 0.7, m
+    assert float(m["t_step1"]) > float(m["t_submit"])
+    assert a.cluster.dns_map(uid) == {}
+    # the PS hosted the variables and wrote its shard under TF's mnist_replica names
+    rd = CheckpointReader(export)
+    assert set(rd.names()) == {"hid_w", "hid_b", "sm_w", "sm_b"}
+    assert tuple(rd.read("hid_w").shape) == (784, 100)
+    assert rd.read("sm_b").abs().sum() > 0
+
+
+def test_mnist_colocated_two_workers(aio):
+    a, port, tmp = aio
+    names = _post(port, {"file": "builtin://mnist_mlp?steps=20&batch=32&placement=colocated&optimizer=momentum&lr=0.05",
+                         "export": str(tmp / "exp"), "detail": {"ps": 1, "worker": 2}})
+    uid = parse_task_name(names[0])[0]
+    rec = _wait_final(a, uid)
+    assert rec["status"] == "succeeded", _logs(a)
+    rd = CheckpointReader(str(tmp / "exp"))
+    assert rd.world == 2 and rd.step == 20
+    assert "hid_w/Momentum" in rd.names()
+    assert int(rd.replicated()["global_step"]) == 20
