@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ResNet-50 synthetic-ImageNet training images/s through the
+sharded parameter-server data plane (BASELINE.json metric / config #2).
+
+    python bench.py                                  # 1 GPU, short defaults
+    python bench.py --gpus 1 --steps 30 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 30 --warmup 10
+
+Every step is a full training step: forward + backward in bf16 NHWC (MIOpen
+convolutions, K7 fused BN/add/ReLU epilogues), K5 bucket pack, RCCL
+reduce-scatter push, K1 fused SGD-momentum shard apply on fp32 master weights,
+RCCL all-gather pull.  Synthetic images/labels, random-init weights.  Weak
+scaling: batch 256 per GPU whatever N.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# upstream tf_cnn_benchmarks parameter_server rows of BASELINE.md (DGX-1 P100, batch 64/GPU, fp32)
+BASELINES = {
+    "resnet50": {1: 219.0, 2: 422.0, 4: 852.0, 8: 1734.0},
+    "inception_v3": {1: 142.0, 2: 284.0, 4: 569.0, 8: 1131.0},
+    "resnet152": {1: 91.8, 2: 181.0, 4: 356.0, 8: 716.0},
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--image-size", type=int, default=0, help="0: model default (224 / 299)")
+    ap.add_argument("--update-mode", default="sync", choices=["sync", "stale"])
+    ap.add_argument("--push", default="reduce_scatter", choices=["reduce_scatter", "all_to_all"])
+    ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("DTF_MIOPEN_FIND", "1")),
+                    help="1: let MIOpen benchmark each conv during warm-up (cudnn.benchmark)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DTF_BENCH_GRAPH", "0")),
+                    help="1: capture the whole step in a hipGraph (single GPU only)")
+    ap.add_argument("--profile-dir", default="")
+    a = ap.parse_args()
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+
+    from distributed_tensorflow_amd.models import get_model_module
+    from distributed_tensorflow_amd.ops import hip
+    from distributed_tensorflow_amd.parallel.comm import Comm
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            print("bench.py: --gpus %d needs torchrun (WORLD_SIZE=%d)" % (a.gpus, world), file=sys.stderr)
+            sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    hip.lib()
+    comm = Comm.from_env()
+    dev = comm.device
+    torch.backends.cudnn.benchmark = bool(a.miopen_find)
+    torch.manual_seed(1234)
+
+    key = a.model.lower().replace("-", "_")
+    mod = get_model_module(key)
+    kw = {}
+    if key.startswith("resnet") and key != "resnet50":
+        kw["depth"] = int(key[6:])
+    model = mod.prepare(mod.build(**kw), dev)
+    model.train()
+    opt = mod.default_optimizer()
+    ps = ShardedPS(list(model.named_parameters()), comm, opt, bucket_mb=a.bucket_mb,
+                   update_mode=a.update_mode, push=a.push)
+    bkw = {"image_size": a.image_size} if a.image_size else {}
+    batch = mod.synthetic_batch(a.batch, device=dev, seed=100 + comm.rank, **bkw)
+
+    def step():
+        loss = mod.loss_fn(model, batch)
+        loss.backward()
+        ps.step()
+        return loss
+
+    graph = None
+    if a.graph and comm.world_size == 1:
+        # warm up eagerly on a side stream (MIOpen find, allocator), then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(max(3, a.warmup)):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        ps.remove_hooks()
+        ps.overlap = False
+        ps.comm_stream = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def step():  # noqa: F811
+            graph.replay()
+            return static_loss
+    for _ in range(a.warmup):
+        loss = step()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if comm.world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    last_loss = float(loss.detach().float().item())
+    n = comm.world_size
+    global_batch = a.batch * n
+    value = global_batch * a.steps / dt
+    base = BASELINES.get(key, {}).get(n)
+    if comm.rank == 0:
+        out = {
+            "metric": "images/sec (whole node) %s synthetic, PS-sharded variables" % a.model,
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None if base is None else round(value / base, 3), "dtype": "bf16",
+            "data": "synthetic images+labels, random-init weights",
+            "config": {"model": a.model + ("_v1.5" if key == "resnet50" else ""), "global_batch": global_batch,
+                       "per_gpu_batch": a.batch, "image_size": a.image_size or ("299" if "inception" in key else 224),
+                       "parallelism": "dp%d+ps-shard%d" % (n, n), "push": a.push, "pull": "all_gather",
+                       "update_mode": a.update_mode, "optimizer": opt.kind, "bucket_mb": a.bucket_mb,
+                       "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find),
+                       "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),
+                       "final_loss": round(last_loss, 4)},
+        }
+        print(json.dumps(out), flush=True)
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

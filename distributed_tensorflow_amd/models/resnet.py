@@ -1,0 +1,145 @@
+"""ResNet-50/101/152 v1 for synthetic ImageNet (config #2; the headline
+``tf_cnn_benchmarks --model=resnet50 --variable_update=parameter_server``
+workload of BASELINE.md).  There is no torchvision in the image, so the network
+is defined here.
+
+MI355X specifics: activations are NHWC (``channels_last``) bf16 end to end;
+convolutions run in MIOpen through PyTorch-ROCm; everything between two
+convolutions -- BatchNorm, the residual add and the ReLU -- is one
+:class:`~distributed_tensorflow_amd.ops.batchnorm.FusedBatchNormAct` layer
+(hand-written gfx950 kernels, K7).  ``version="v1.5"`` (default) puts the
+stride on the 3x3 convolution (the MLPerf / torchvision variant, 4.1 GMACs);
+``"v1"`` puts it on the first 1x1 like the original (3.8 GMACs).
+
+Variables are named like TF-slim's ``resnet_v1_50`` for checkpoints
+(``tf_variable_names``): ``resnet_v1_50/block2/unit_3/bottleneck_v1/conv2/weights``,
+``.../BatchNorm/gamma|beta|moving_mean|moving_variance``, ``resnet_v1_50/logits/...``.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops.batchnorm import FusedBatchNormAct
+
+_DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def _conv(i, o, k, stride=1):
+    return nn.Conv2d(i, o, k, stride=stride, padding=k // 2, bias=False)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, v15):
+        super().__init__()
+        out = planes * self.expansion
+        self.conv1 = _conv(inplanes, planes, 1, 1 if v15 else stride)
+        self.bn1 = FusedBatchNormAct(planes, relu=True)
+        self.conv2 = _conv(planes, planes, 3, stride if v15 else 1)
+        self.bn2 = FusedBatchNormAct(planes, relu=True)
+        self.conv3 = _conv(planes, out, 1)
+        self.bn3 = FusedBatchNormAct(out, relu=True)          # fused: BN + shortcut add + ReLU
+        if stride != 1 or inplanes != out:
+            self.shortcut_conv = _conv(inplanes, out, 1, stride)
+            self.shortcut_bn = FusedBatchNormAct(out, relu=False)
+        else:
+            self.shortcut_conv = None
+
+    def forward(self, x):
+        sc = x if self.shortcut_conv is None else self.shortcut_bn(self.shortcut_conv(x))
+        y = self.bn1(self.conv1(x))
+        y = self.bn2(self.conv2(y))
+        return self.bn3(self.conv3(y), sc)
+
+
+class ResNet(nn.Module):
+    def __init__(self, depth=50, num_classes=1000, version="v1.5", zero_init_residual=False):
+        super().__init__()
+        self.depth = depth
+        v15 = version in ("v1.5", "1.5", "v15")
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FusedBatchNormAct(64, relu=True)
+        blocks, inplanes = [], 64
+        for stage, n in enumerate(_DEPTHS[depth]):
+            planes = 64 << stage
+            units = []
+            for u in range(n):
+                units.append(Bottleneck(inplanes, planes, 2 if (u == 0 and stage > 0) else 1, v15))
+                inplanes = planes * 4
+            blocks.append(nn.Sequential(*units))
+        self.block1, self.block2, self.block3, self.block4 = blocks
+        self.fc = nn.Linear(inplanes, num_classes)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.zeros_(m.bn3.weight)
+
+    def forward(self, x):
+        x = self.bn1(self.conv1(x))
+        x = F.max_pool2d(x, 3, 2, 1)
+        x = self.block4(self.block3(self.block2(self.block1(x))))
+        x = x.mean((2, 3))
+        return self.fc(x)
+
+
+def build(depth=50, version="v1.5", num_classes=1000, **_):
+    return ResNet(int(depth), int(num_classes), version)
+
+
+def prepare(model, device):
+    device = torch.device(device)
+    if device.type == "cuda":
+        return model.to(device=device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    return model.to(device)
+
+
+def tf_variable_names(model):
+    scope = "resnet_v1_%d" % model.depth
+    bn = {"weight": "gamma", "bias": "beta", "running_mean": "moving_mean", "running_var": "moving_variance"}
+    out = {}
+    names = [n for n, _ in model.named_parameters()] + [n for n, _ in model.named_buffers()]
+    for n in names:
+        parts = n.split(".")
+        if parts[0] == "conv1":
+            tf = "conv1/weights"
+        elif parts[0] == "bn1":
+            tf = "conv1/BatchNorm/" + bn[parts[1]]
+        elif parts[0] == "fc":
+            tf = "logits/" + ("weights" if parts[1] == "weight" else "biases")
+        else:
+            unit = "%s/unit_%d/bottleneck_v1/" % (parts[0], int(parts[1]) + 1)
+            layer, leaf = parts[2], parts[3]
+            if layer.startswith("shortcut"):
+                tf = unit + "shortcut/" + ("weights" if layer.endswith("conv") else "BatchNorm/" + bn[leaf])
+            elif layer.startswith("conv"):
+                tf = unit + layer + "/weights"
+            else:
+                tf = unit + "conv" + layer[2:] + "/BatchNorm/" + bn[leaf]
+        out[n] = scope + "/" + tf
+    return out
+
+
+def synthetic_batch(batch, device="cpu", dtype=None, seed=None, image_size=224, num_classes=1000, **_):
+    device = torch.device(device)
+    g = torch.Generator().manual_seed(seed) if seed is not None else None
+    dtype = dtype or (torch.bfloat16 if device.type == "cuda" else torch.float32)
+    x = torch.randn(batch, 3, image_size, image_size, generator=g).to(device=device, dtype=dtype)
+    x = x.contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, num_classes, (batch,), generator=g).to(device)
+    return x, y
+
+
+def loss_fn(model, batch):
+    x, y = batch
+    return F.cross_entropy(model(x).float(), y)
+
+
+def default_optimizer():
+    from ..parallel.ps_runtime import OptimizerSpec
+
+    # tf_cnn_benchmarks defaults: momentum 0.9, weight decay 4e-5 (1e-4 is the ImageNet norm)
+    return OptimizerSpec(kind="momentum", lr=0.1, momentum=0.9, weight_decay=1e-4)

@@ -1,0 +1,179 @@
+"""Fused BatchNorm (+ residual add) (+ ReLU) conv epilogue (kernel K7).
+
+``FusedBatchNormAct`` is the layer the conv nets of ``models/`` put after every
+convolution.  On an MI355X with NHWC bf16 activations it runs the hand-written
+kernels of ``csrc/bn_kernels.hip`` (forward: statistics + one fused apply pass;
+backward: one reduce pass + one fused apply pass).  Elsewhere (CPU, fp32,
+NCHW) it is the plain PyTorch composition ``relu(batch_norm(x) + residual)``,
+which is also the oracle for the kernel tests.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = hip.lib()
+    if not _declared:
+        P, I, L, Fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+        hip.declare("dtf_bn_partial_floats", [L, I], L)
+        hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, P])
+        hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, L, I, I, P])
+        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, L, I, I, P])
+        _declared = True
+    return lib
+
+
+_partial_ws = {}
+
+
+def _partial(device, M, C):
+    need = int(_lib().dtf_bn_partial_floats(M, C))
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _partial_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=device)
+        _partial_ws[key] = ws
+    return ws
+
+
+def _nhwc_rows(x):
+    """``x`` -> (M, C) if it is a dense NHWC (channels_last) 4-D tensor or a
+    contiguous 2-D [M, C] tensor; else None."""
+    if x.dim() == 4:
+        N, C, H, W = x.shape
+        if x.is_contiguous(memory_format=torch.channels_last):
+            return N * H * W, C
+        return None
+    if x.dim() == 2 and x.is_contiguous():
+        return x.shape[0], x.shape[1]
+    return None
+
+
+def kernel_eligible(x, weight):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype in (torch.bfloat16, torch.float32)
+            and _nhwc_rows(x) is not None and x.shape[1] % 8 == 0 and x.shape[1] <= 5000 and x.numel() > 0)
+
+
+class _FusedBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
+        lib = _lib()
+        M, C = _nhwc_rows(x)
+        dev = x.device
+        y = torch.empty_like(x)
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+        if residual is not None:
+            assert residual.shape == x.shape and residual.dtype == x.dtype and _nhwc_rows(residual) is not None
+        rc = lib.dtf_bn_fwd_train(
+            hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
+            hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
+            stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+            hip.ptr(_partial(dev, M, C)), M, C, int(relu), hip.stream())
+        hip.check(rc, "dtf_bn_fwd_train")
+        ctx.save_for_backward(x, y if relu else None, weight, stats)
+        ctx.relu, ctx.has_res, ctx.dims = bool(relu), residual is not None, (M, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, stats = ctx.saved_tensors
+        M, C = ctx.dims
+        lib = _lib()
+        dev = x.device
+        if _nhwc_rows(dy) is None or dy.stride() != x.stride():
+            dy = dy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
+        coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+        rc = lib.dtf_bn_bwd_train(
+            hip.ptr(dy), hip.ptr(x), hip.ptr(y), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
+            stats[1].data_ptr(), hip.ptr(dx), hip.ptr(dres), dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef),
+            hip.ptr(_partial(dev, M, C)), M, C, int(ctx.relu), hip.stream())
+        hip.check(rc, "dtf_bn_bwd_train")
+        return dx, dgb[0], dgb[1], dres, None, None, None, None, None
+
+
+def bn_act_reference(x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
+    y = F.batch_norm(x, running_mean, running_var, weight, bias, training, momentum, eps)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def fused_bn_act(x, weight, bias, residual=None, running_mean=None, running_var=None, training=True,
+                 momentum=0.1, eps=1e-5, relu=True):
+    """``[relu]( batch_norm(x) [+ residual] )``."""
+    if not kernel_eligible(x, weight):
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and \
+                not x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0:
+            x = x.contiguous(memory_format=torch.channels_last)     # keep the conv nets on the kernel path
+            if residual is not None:
+                residual = residual.contiguous(memory_format=torch.channels_last)
+        else:
+            w, b = weight, bias
+            if x.dtype != weight.dtype and not x.is_cuda:
+                w, b = weight.to(x.dtype), bias.to(x.dtype)
+            return bn_act_reference(x, w, b, residual, running_mean, running_var, training, momentum, eps, relu)
+    if training:
+        return _FusedBNAct.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu)
+    # inference: statistics are constants -> a single fused apply pass
+    lib = _lib()
+    M, C = _nhwc_rows(x)
+    scale = weight.float() * torch.rsqrt(running_var.float() + eps)
+    shift = bias.float() - running_mean.float() * scale
+    y = torch.empty_like(x)
+    rc = lib.dtf_bn_fwd_apply(hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(scale), hip.ptr(shift), M, C,
+                              int(relu), hip.stream())
+    hip.check(rc, "dtf_bn_fwd_apply")
+    return y
+
+
+class FusedBatchNormAct(nn.Module):
+    """BatchNorm2d/1d + optional residual + optional ReLU in one layer.
+    Parameter names follow ``nn.BatchNorm2d`` (``weight``=gamma, ``bias``=beta,
+    ``running_mean``/``running_var`` kept in fp32 whatever the model dtype)."""
+
+    def __init__(self, num_features, relu=True, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.relu, self.eps, self.momentum = num_features, relu, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features, dtype=torch.float32))
+        self.register_buffer("running_var", torch.ones(num_features, dtype=torch.float32))
+
+    def _apply(self, fn, recurse=True):
+        # keep the moving statistics in fp32 when the model is cast to bf16
+        rm, rv = self.running_mean, self.running_var
+        super()._apply(fn, recurse)
+        for name, old in (("running_mean", rm), ("running_var", rv)):
+            new = getattr(self, name)
+            if new.dtype != torch.float32:
+                setattr(self, name, new.float())
+        return self
+
+    def forward(self, x, residual=None):
+        rm, rv = self.running_mean, self.running_var
+        if not x.is_cuda and x.dtype != torch.float32:
+            rm, rv = rm.to(x.dtype), rv.to(x.dtype)
+            y = bn_act_reference(x, self.weight.to(x.dtype), self.bias.to(x.dtype), residual, rm, rv,
+                                 self.training, self.momentum, self.eps, self.relu)
+            if self.training:
+                self.running_mean.copy_(rm)
+                self.running_var.copy_(rv)
+            return y
+        return fused_bn_act(x, self.weight, self.bias, residual, rm, rv, self.training, self.momentum,
+                            self.eps, self.relu)
+
+    def extra_repr(self):
+        return "%d, relu=%s, eps=%g, momentum=%g" % (self.num_features, self.relu, self.eps, self.momentum)

@@ -1,0 +1,399 @@
+// K7: conv epilogues for gfx950 -- training-mode BatchNorm fused with the
+// residual add and the ReLU that follow a convolution, NHWC bf16 (SURVEY 2.4;
+// replaces TF's FusedBatchNorm + Add + Relu on the worker).  The convolution
+// itself stays in MIOpen; everything between two convolutions is these kernels.
+//
+// The tensor is viewed as [M = N*H*W rows][C channels], channels innermost.
+// All kernels are HBM-bound; the point of the fusion is the pass count:
+//
+//   forward   stats   : read x                      (2 B/elem)
+//             apply   : read x (+res), write y      (4-6 B/elem)
+//   backward  reduce  : read dy, x, y               (6 B/elem)
+//             apply   : read dy, x, y, write dx (+dres)   (8-10 B/elem)
+//
+// against ~26-38 B/elem for separate BN / add / ReLU ops.
+//
+// Reductions are two-stage and deterministic: a [row-chunk][channel-tile] grid
+// writes per-block partial sums, a small finalize kernel adds them in fixed
+// order (no float atomics -> bitwise reproducible statistics).
+//
+// Thread mapping of the streaming kernels: a 256-thread block covers a tile of
+// 64 channels (8 lanes x 8 channels = one 128-B line per row) x 32 rows per
+// iteration, 4 iterations unrolled so every lane keeps 4-8 16-B loads in flight.
+#include "dtf_common.h"
+
+#define BN_CT 64          // channels per block tile
+#define BN_ROWS 32        // rows per block iteration
+#define BN_UNROLL 4
+
+enum { BN_FWD_STATS = 0, BN_BWD_RELU = 1, BN_BWD_PLAIN = 2 };
+
+__device__ __forceinline__ void ld8bf(const unsigned short* p, float (&v)[8]) {
+    u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[2 * k] = __uint_as_float(r[k] << 16);
+        v[2 * k + 1] = __uint_as_float(r[k] & 0xffff0000u);
+    }
+}
+
+__device__ __forceinline__ void st8bf(unsigned short* p, const float (&v)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+    *reinterpret_cast<u32x4*>(p) = r;
+}
+
+// partial[(blockIdx.x * 2 + stat) * C + c]
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __restrict__ x,
+                                                        const unsigned short* __restrict__ dy,
+                                                        const unsigned short* __restrict__ y,
+                                                        const float* __restrict__ mean,
+                                                        float* __restrict__ partial, int64_t M, int C,
+                                                        int rows_per_block) {
+    const int tx = threadIdx.x & 7;
+    const int ty = threadIdx.x >> 3;
+    const int c0 = blockIdx.y * BN_CT + tx * 8;
+    const bool cvalid = c0 < C;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s1[8], s2[8], mu[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; }
+    if (MODE != BN_FWD_STATS && cvalid) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mu[k] = mean[c0 + k];
+    }
+    if (cvalid) {
+        for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+            float xv[BN_UNROLL][8], dv[BN_UNROLL][8], yv[BN_UNROLL][8];
+            bool ok[BN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                const int64_t row = r + (int64_t)u * BN_ROWS;
+                ok[u] = row < r1;
+                if (ok[u]) {
+                    const int64_t off = row * C + c0;
+                    ld8bf(x + off, xv[u]);
+                    if (MODE != BN_FWD_STATS) ld8bf(dy + off, dv[u]);
+                    if (MODE == BN_BWD_RELU) ld8bf(y + off, yv[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                if (!ok[u]) continue;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (MODE == BN_FWD_STATS) {
+                        s1[k] += xv[u][k];
+                        s2[k] = fmaf(xv[u][k], xv[u][k], s2[k]);
+                    } else {
+                        float d = dv[u][k];
+                        if (MODE == BN_BWD_RELU) d = yv[u][k] > 0.f ? d : 0.f;
+                        s1[k] += d;
+                        s2[k] = fmaf(d, xv[u][k] - mu[k], s2[k]);
+                    }
+                }
+            }
+        }
+    }
+    // lanes with equal (lane & 7) hold the same channels: fold lane bits 3..5
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            s1[k] += __shfl_xor(s1[k], o, 64);
+            s2[k] += __shfl_xor(s2[k], o, 64);
+        }
+    }
+    __shared__ float red[4][2][BN_CT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[wave][0][lane * 8 + k] = s1[k];
+            red[wave][1][lane * 8 + k] = s2[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * BN_CT) {
+        const int stat = threadIdx.x / BN_CT, cc = threadIdx.x % BN_CT;
+        const int c = blockIdx.y * BN_CT + cc;
+        if (c < C) {
+            float s = red[0][stat][cc] + red[1][stat][cc] + red[2][stat][cc] + red[3][stat][cc];
+            partial[((int64_t)blockIdx.x * 2 + stat) * C + c] = s;
+        }
+    }
+}
+
+// One block finalizes 16 channels: 16 channel lanes x 16 partial-row lanes.
+__device__ __forceinline__ void reduce_partials16(const float* partial, int nblk, int C, int c, bool valid,
+                                                  float& o1, float& o2) {
+    const int rl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+    float a1 = 0.f, a2 = 0.f;
+    if (valid)
+        for (int j = rl; j < nblk; j += 16) {
+            a1 += partial[((int64_t)j * 2 + 0) * C + c];
+            a2 += partial[((int64_t)j * 2 + 1) * C + c];
+        }
+    __shared__ float r1[16][17], r2[16][17];
+    r1[rl][cl] = a1;
+    r2[rl][cl] = a2;
+    __syncthreads();
+    o1 = 0.f; o2 = 0.f;
+    if (rl == 0) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { o1 += r1[j][cl]; o2 += r2[j][cl]; }
+    }
+}
+
+template <int PDT>
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              float inv_count, float unbias, const void* gamma,
+                                                              const void* beta, float* running_mean,
+                                                              float* running_var, float momentum, float eps,
+                                                              float* mean_out, float* invstd_out,
+                                                              float* scale_out, float* shift_out) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool valid = c < C;
+    float s1, s2;
+    reduce_partials16(partial, nblk, C, c, valid, s1, s2);
+    if ((threadIdx.x >> 4) == 0 && valid) {
+        const double m = (double)s1 * inv_count;
+        double var = (double)s2 * inv_count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m;
+        const float invstd = rsqrtf((float)var + eps);
+        const float g = load1<PDT>(gamma, c), b = load1<PDT>(beta, c);
+        mean_out[c] = mean;
+        invstd_out[c] = invstd;
+        const float sc = g * invstd;
+        scale_out[c] = sc;
+        shift_out[c] = fmaf(-mean, sc, b);
+        if (running_mean) {
+            running_mean[c] = fmaf(momentum, mean - running_mean[c], running_mean[c]);
+            running_var[c] = fmaf(momentum, (float)var * unbias - running_var[c], running_var[c]);
+        }
+    }
+}
+
+// dgamma, dbeta + the three per-channel coefficients of the elementwise pass:
+//   dx = k1*dy' + k2*x + k3,  k1 = g*invstd, k2 = -k1*invstd*S2/M * invstd... (see below)
+template <int PDT>
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                              float inv_count, const void* gamma,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, void* dgamma,
+                                                              void* dbeta, float* coef /* [3][C] */) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const bool valid = c < C;
+    float s1, s2;   // s1 = sum dy', s2 = sum dy' * (x - mean)
+    reduce_partials16(partial, nblk, C, c, valid, s1, s2);
+    if ((threadIdx.x >> 4) == 0 && valid) {
+        const float is = invstd[c], mu = mean[c], g = load1<PDT>(gamma, c);
+        const float dg = s2 * is;            // sum dy' * xhat
+        store1<PDT>(dgamma, c, dg);
+        store1<PDT>(dbeta, c, s1);
+        // dx = g*is * (dy' - s1/M - xhat * dg/M),  xhat = (x - mu) * is
+        const float k1 = g * is;
+        const float k2 = -k1 * is * dg * inv_count;
+        const float k3 = -k1 * s1 * inv_count - k2 * mu;
+        coef[c] = k1;
+        coef[C + c] = k2;
+        coef[2 * C + c] = k3;
+    }
+}
+
+// y = [relu]( x*scale[c] + shift[c] [+ res] ); coefficient vectors staged in LDS.
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const unsigned short* __restrict__ x,
+                                                           const unsigned short* __restrict__ res,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           unsigned short* __restrict__ y, int64_t nvec, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* lsc = lds;
+    float* lsh = lds + C;
+    for (int i = threadIdx.x; i < C; i += 256) { lsc[i] = scale[i]; lsh[i] = shift[i]; }
+    __syncthreads();
+    const int cvec = C >> 3;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+        const int c0 = (int)(v % cvec) << 3;
+        float xv[8], rv[8];
+        ld8bf(x + (v << 3), xv);
+        if (RES) ld8bf(res + (v << 3), rv);
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(lsc + c0), sb = *reinterpret_cast<const f32x4*>(lsc + c0 + 4);
+        const f32x4 ha = *reinterpret_cast<const f32x4*>(lsh + c0), hb = *reinterpret_cast<const f32x4*>(lsh + c0 + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float sc = k < 4 ? sa[k] : sb[k - 4], sh = k < 4 ? ha[k] : hb[k - 4];
+            float o = fmaf(xv[k], sc, sh);
+            if (RES) o += rv[k];
+            if (RELU) o = fmaxf(o, 0.f);
+            xv[k] = o;
+        }
+        st8bf(y + (v << 3), xv);
+    }
+}
+
+// dx = k1*dy' + k2*x + k3 ; dres = dy'   (dy' = dy masked by y > 0 when RELU)
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy,
+                                                           const unsigned short* __restrict__ x,
+                                                           const unsigned short* __restrict__ y,
+                                                           const float* __restrict__ coef,
+                                                           unsigned short* __restrict__ dx,
+                                                           unsigned short* __restrict__ dres, int64_t nvec, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < 3 * C; i += 256) lds[i] = coef[i];
+    __syncthreads();
+    const float* l1 = lds;
+    const float* l2 = lds + C;
+    const float* l3 = lds + 2 * C;
+    const int cvec = C >> 3;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+        const int c0 = (int)(v % cvec) << 3;
+        float dv[8], xv[8], yv[8];
+        ld8bf(dy + (v << 3), dv);
+        ld8bf(x + (v << 3), xv);
+        if (RELU) ld8bf(y + (v << 3), yv);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(l1 + c0), a1 = *reinterpret_cast<const f32x4*>(l1 + c0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(l2 + c0), b1 = *reinterpret_cast<const f32x4*>(l2 + c0 + 4);
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(l3 + c0), d1 = *reinterpret_cast<const f32x4*>(l3 + c0 + 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float k1 = k < 4 ? a0[k] : a1[k - 4], k2 = k < 4 ? b0[k] : b1[k - 4], k3 = k < 4 ? d0[k] : d1[k - 4];
+            float d = dv[k];
+            if (RELU) d = yv[k] > 0.f ? d : 0.f;
+            dv[k] = d;
+            xv[k] = fmaf(k1, d, fmaf(k2, xv[k], k3));
+        }
+        st8bf(dx + (v << 3), xv);
+        if (RES) st8bf(dres + (v << 3), dv);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, int* ctiles) {
+    const int ct = (C + BN_CT - 1) / BN_CT;
+    int64_t want = 1024 / ct;                 // ~4 blocks per CU in total
+    if (want < 1) want = 1;
+    const int64_t quantum = BN_ROWS * BN_UNROLL;
+    int64_t max_blocks = (M + quantum - 1) / quantum;
+    if (want > max_blocks) want = max_blocks;
+    int64_t rpb = (M + want - 1) / want;
+    rpb = (rpb + BN_ROWS - 1) / BN_ROWS * BN_ROWS;
+    *rows_per_block = (int)rpb;
+    *nblk_x = (int)((M + rpb - 1) / rpb);
+    *ctiles = ct;
+}
+
+extern "C" {
+
+// workspace query: floats needed for the partial sums of an [M, C] reduction
+int64_t dtf_bn_partial_floats(int64_t M, int C) {
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    return (int64_t)nb * 2 * C;
+}
+
+// Training forward.  x,y,res: bf16 [M,C]; gamma/beta: param dtype; running_*: fp32 or null;
+// mean/invstd/scale/shift: fp32 [C] outputs; partial: workspace.
+int dtf_bn_fwd_train(const void* x, const void* res, void* y, const void* gamma, const void* beta, int param_dtype,
+                     float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                     float* invstd, float* scale, float* shift, float* partial, int64_t M, int C, int relu,
+                     hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0) return -20;
+    if (2 * C * sizeof(float) > 64 * 1024) return -21;
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS>), dim3(nb, ct), dim3(256), 0, stream,
+                       (const unsigned short*)x, nullptr, nullptr, nullptr, partial, M, C, rpb);
+    const float inv_count = 1.0f / (float)M;
+    const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    const int fgrid = (C + 15) / 16;
+    if (param_dtype == DTF_BF16)
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
+                           inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                           scale, shift);
+    else
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
+                           inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                           scale, shift);
+    const int64_t nvec = M * C / 8;
+    const int grid = dtf_stream_grid(nvec, 256);
+    const size_t lds = 2 * C * sizeof(float);
+    const unsigned short *xs = (const unsigned short*)x, *rs = (const unsigned short*)res;
+    unsigned short* ys = (unsigned short*)y;
+#define FWD(R, S) hipLaunchKernelGGL((bn_fwd_apply_kernel<R, S>), dim3(grid), dim3(256), lds, stream, xs, rs, scale, shift, ys, nvec, C)
+    if (relu) { if (res) FWD(true, true); else FWD(true, false); }
+    else { if (res) FWD(false, true); else FWD(false, false); }
+#undef FWD
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Inference / frozen-statistics forward: scale/shift precomputed by the caller.
+int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t M,
+                     int C, int relu, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0) return -20;
+    if (2 * C * sizeof(float) > 64 * 1024) return -21;
+    const int64_t nvec = M * C / 8;
+    const int grid = dtf_stream_grid(nvec, 256);
+    const size_t lds = 2 * C * sizeof(float);
+    const unsigned short *xs = (const unsigned short*)x, *rs = (const unsigned short*)res;
+    unsigned short* ys = (unsigned short*)y;
+#define FWD(R, S) hipLaunchKernelGGL((bn_fwd_apply_kernel<R, S>), dim3(grid), dim3(256), lds, stream, xs, rs, scale, shift, ys, nvec, C)
+    if (relu) { if (res) FWD(true, true); else FWD(true, false); }
+    else { if (res) FWD(false, true); else FWD(false, false); }
+#undef FWD
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Training backward.  dres may be null (no residual branch).  coef: fp32 [3*C] workspace.
+int dtf_bn_bwd_train(const void* dy, const void* x, const void* y, const void* gamma, int param_dtype,
+                     const float* mean, const float* invstd, void* dx, void* dres, void* dgamma, void* dbeta,
+                     float* coef, float* partial, int64_t M, int C, int relu, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0) return -20;
+    if (3 * C * sizeof(float) > 64 * 1024) return -21;
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x,
+                         *ys = (const unsigned short*)y;
+    if (relu)
+        hipLaunchKernelGGL((bn_reduce_kernel<BN_BWD_RELU>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ys, mean,
+                           partial, M, C, rpb);
+    else
+        hipLaunchKernelGGL((bn_reduce_kernel<BN_BWD_PLAIN>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ys, mean,
+                           partial, M, C, rpb);
+    const float inv_count = 1.0f / (float)M;
+    const int fgrid = (C + 15) / 16;
+    if (param_dtype == DTF_BF16)
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
+                           inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
+    else
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
+                           inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
+    const int64_t nvec = M * C / 8;
+    const int grid = dtf_stream_grid(nvec, 256);
+    const size_t lds = 3 * C * sizeof(float);
+    unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
+#define BWD(R, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, S>), dim3(grid), dim3(256), lds, stream, dys, xs, ys, coef, dxs, drs, nvec, C)
+    if (relu) { if (dres) BWD(true, true); else BWD(true, false); }
+    else { if (dres) BWD(false, true); else BWD(false, false); }
+#undef BWD
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

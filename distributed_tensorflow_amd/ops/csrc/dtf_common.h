@@ -97,6 +97,10 @@ static inline int dtf_stream_grid(int64_t work_items, int block) {
     return (int)b;
 }
 
+// hipGetLastError() reports the last error of ANY runtime call of this thread
+// (e.g. a benign probe inside MIOpen), so entry points clear it first.
+#define DTF_CLEAR_ERRORS() (void)hipGetLastError()
+
 #define DTF_CHECK_LAUNCH()                                     \
     do {                                                       \
         hipError_t e__ = hipGetLastError();                    \

@@ -297,6 +297,7 @@ int dtf_sgd_momentum_apply(const void* g, int g_dtype, int nsrc, int64_t src_str
                            void* p_out, int out_dtype, int64_t n, const float* hyper, const float* gnorm_sq,
                            float lr, float momentum, float wd, float grad_scale, float max_norm, int nesterov,
                            hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
     if (n <= 0) return 0;
     if (!aligned16(g) || !aligned16(p32) || !aligned16(m) || !aligned16(p_out)) return -16;
     if (nsrc > 1 && (src_stride & 7)) return -17;
@@ -314,6 +315,7 @@ int dtf_adam_apply(const void* g, int g_dtype, int nsrc, int64_t src_stride, flo
                    void* p_out, int out_dtype, int64_t n, const float* hyper, const float* gnorm_sq, float lr,
                    float beta1, float beta2, float eps, float wd, float grad_scale, float max_norm, float step,
                    int adamw, int bias_correction, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
     if (n <= 0) return 0;
     if (!aligned16(g) || !aligned16(p32) || !aligned16(m) || !aligned16(v) || !aligned16(p_out)) return -16;
     if (nsrc > 1 && (src_stride & 7)) return -17;
@@ -332,6 +334,7 @@ int dtf_adam_apply(const void* g, int g_dtype, int nsrc, int64_t src_stride, flo
 int dtf_bucket_pack(int ntensors, const void* const* ptrs, const int64_t* numel, const int64_t* flat_off,
                     const int32_t* dtypes, void* flat, int flat_dtype, float scale, int unpack,
                     hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
     int done = 0;
     while (done < ntensors) {
         PackTable t;
@@ -367,6 +370,7 @@ int dtf_bucket_pack(int ntensors, const void* const* ptrs, const int64_t* numel,
 // partials: workspace of >= 2048 floats.  out[0] (+)= sum(x^2)
 int dtf_sumsq(const void* x, int dtype, int64_t n, float* partials, float* out, int accumulate,
               hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
     if (!aligned16(x)) return -16;
     const int grid = dtf_stream_grid(n >> 3, 256);
     if (dtype == DTF_BF16) hipLaunchKernelGGL((sumsq_partial_kernel<DTF_BF16>), dim3(grid), dim3(256), 0, stream, x, n, partials);
@@ -378,6 +382,7 @@ int dtf_sumsq(const void* x, int dtype, int64_t n, float* partials, float* out, 
 
 int dtf_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, float scale,
                    hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
     if (n <= 0) return 0;
     if (!aligned16(src) || !aligned16(dst)) return -16;
     const int grid = dtf_stream_grid(n >> 3, 256);
@@ -388,6 +393,7 @@ int dtf_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype, int
     return 0;
 }
 
-int dtf_abi_version() { return 1; }
+int dtf_abi_version() {
+    DTF_CLEAR_ERRORS(); return 1; }
 
 }  // extern "C"

@@ -1,0 +1,215 @@
+"""Numerics of the hand-written gfx950 kernels against plain PyTorch fp32
+references of the same op (SURVEY 4.1 'Kernel numerics').  Needs an MI355X."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from distributed_tensorflow_amd.ops import batchnorm, bucket, hip, optim, reduce  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    assert hip.available(), "libdtf_hip.so missing: build with python -m distributed_tensorflow_amd.ops.build"
+    hip.lib()
+    return torch.device("cuda", 0)
+
+
+def _mk(n, dev, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, generator=g).to(device=dev, dtype=dtype)
+
+
+@pytest.mark.parametrize("n", [8, 1000, 4096 + 3, 1 << 20, (1 << 22) + 8])
+@pytest.mark.parametrize("gdt,odt", [(torch.bfloat16, torch.bfloat16), (torch.float32, torch.float32),
+                                     (torch.bfloat16, torch.float32), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_sgd_momentum_apply(dev, n, gdt, odt, nesterov):
+    g = _mk(n, dev, gdt, 1)
+    p = _mk(n, dev, torch.float32, 2)
+    m = _mk(n, dev, torch.float32, 3) * 0.1
+    out = torch.zeros(n, dtype=odt, device=dev)
+    pr, mr, outr = p.clone(), m.clone(), torch.zeros(n, dtype=odt, device=dev)
+    kw = dict(lr=0.05, momentum=0.9, wd=1e-4, nesterov=nesterov, grad_scale=0.125)
+    optim.sgd_momentum_apply(g, p, m, out, **kw)
+    optim.sgd_momentum_reference(g, pr, mr, outr, **kw)
+    torch.testing.assert_close(p, pr, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m, mr, rtol=1e-5, atol=1e-6)
+    if odt == torch.float32:
+        torch.testing.assert_close(out, outr, rtol=1e-5, atol=1e-6)
+    else:
+        torch.testing.assert_close(out.float(), outr.float(), rtol=1e-2, atol=1e-2)
+        # the wire copy is the RNE rounding of the master value
+        assert (out == p.to(torch.bfloat16)).all()
+
+
+@pytest.mark.parametrize("nsrc", [2, 8])
+def test_sgd_momentum_fused_source_sum(dev, nsrc):
+    n = 8 * 1000
+    g = _mk(n * nsrc, dev, torch.bfloat16, 5)
+    p, m = _mk(n, dev, torch.float32, 6), torch.zeros(n, device=dev)
+    pr, mr = p.clone(), m.clone()
+    out = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    kw = dict(lr=0.1, momentum=0.9, nsrc=nsrc, src_stride=n)
+    optim.sgd_momentum_apply(g, p, m, out, **kw)
+    optim.sgd_momentum_reference(g, pr, mr, None, **kw)
+    torch.testing.assert_close(p, pr, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [8, 4096 + 5, 1 << 21])
+@pytest.mark.parametrize("adamw", [True, False])
+def test_adam_apply(dev, n, adamw):
+    g = _mk(n, dev, torch.bfloat16, 1)
+    p, m, v = _mk(n, dev, torch.float32, 2), _mk(n, dev, torch.float32, 3) * 0.01, _mk(n, dev, torch.float32, 4).abs() * 1e-3
+    out = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    kw = dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-6, wd=0.01, adamw=adamw, step=7, grad_scale=0.5)
+    optim.adam_apply(g, p, m, v, out, **kw)
+    optim.adam_reference(g, pr, mr, vr, None, **kw)
+    torch.testing.assert_close(p, pr, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(m, mr, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(v, vr, rtol=1e-4, atol=1e-9)
+
+
+def test_adam_hyper_from_device_and_clip(dev):
+    n = 8 * 513
+    g = _mk(n, dev, torch.float32, 1)
+    p, m, v = _mk(n, dev, torch.float32, 2), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    pr, mr, vr = p.clone(), m.clone(), v.clone()
+    hyper = torch.tensor([3e-3, 0.25, 4.0], device=dev)
+    gn = torch.zeros(1, device=dev)
+    reduce.sumsq(g, gn)
+    torch.testing.assert_close(gn[0], (g.double() ** 2).sum().float(), rtol=1e-5, atol=0)
+    kw = dict(lr=99.0, hyper=hyper, gnorm_sq=gn, max_norm=1.0, step=123)
+    optim.adam_apply(g, p, m, v, None, **kw)
+    optim.adam_reference(g, pr, mr, vr, None, **kw)
+    torch.testing.assert_close(p, pr, rtol=2e-5, atol=1e-6)
+
+
+def test_bucket_pack_unpack_many_tensors(dev):
+    torch.manual_seed(0)
+    shapes = [(64, 3, 7, 7), (64,), (64,), (256, 64, 1, 1), (13,), (1000, 2048), (1,), (5, 3)] * 30   # 240 tensors
+    tensors, offs, off = [], [], 0
+    for i, s in enumerate(shapes):
+        dt = torch.float32 if i % 3 == 0 else torch.bfloat16
+        t = torch.randn(*s, device=dev).to(dt)
+        if len(s) == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        tensors.append(t)
+        offs.append(off)
+        off += (t.numel() + 7) // 8 * 8
+    plan = bucket.PackPlan([t.numel() for t in tensors], offs)
+    for fdt in (torch.bfloat16, torch.float32):
+        flat = torch.full((off,), 7.0, dtype=fdt, device=dev)
+        plan.pack(tensors, flat, 0.5)
+        for t, o in zip(tensors, offs):
+            ref = (bucket.dense_storage_view(t).float() * 0.5).to(fdt)
+            assert torch.equal(flat[o:o + t.numel()], ref)
+        outs = [torch.zeros_like(t) for t in tensors]
+        plan.unpack(flat, outs)
+        for t, o in zip(outs, tensors):
+            torch.testing.assert_close(t.float(), (o.float() * 0.5).to(fdt).to(o.dtype).float(), rtol=1e-2, atol=1e-2)
+
+
+def test_cast_scale_and_sumsq(dev):
+    for n in (8, 1025, 1 << 20):
+        x = _mk(n, dev, torch.float32, 9)
+        y = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        reduce.cast_scale(x, y, 2.0)
+        assert torch.equal(y, (x * 2).to(torch.bfloat16))
+        out = torch.zeros(1, device=dev)
+        reduce.sumsq(y, out)
+        reduce.sumsq(y, out, accumulate=True)
+        torch.testing.assert_close(out[0], 2 * (y.double() ** 2).sum().float(), rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 56, 56), (4, 256, 14, 14), (2, 2048, 7, 7), (3, 192, 17, 17),
+                                   (2, 48, 35, 35), (2, 8, 1, 3)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("pdt", [torch.bfloat16, torch.float32])
+def test_fused_bn_act_matches_pytorch(dev, shape, relu, res, pdt):
+    torch.manual_seed(1)
+    N, C, H, W = shape
+    x = (torch.randn(shape, device=dev) * 2 + 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if res else None
+    w = (torch.rand(C, device=dev) + 0.5).to(pdt)
+    b = (torch.randn(C, device=dev) * 0.1).to(pdt)
+    dy = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+
+    x1, w1, b1 = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    r1 = r.clone().requires_grad_() if res else None
+    y1 = batchnorm.fused_bn_act(x1, w1, b1, r1, rm, rv, True, 0.1, 1e-5, relu)
+    y1.backward(dy)
+
+    # fp32 reference of the same op
+    x2, w2, b2 = x.float().requires_grad_(), w.float().requires_grad_(), b.float().requires_grad_()
+    r2 = r.float().requires_grad_() if res else None
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    pre = batchnorm.bn_act_reference(x2, w2, b2, r2, rm2, rv2, True, 0.1, 1e-5, False)
+    if relu:
+        # An element whose pre-activation is within fp32 rounding of 0 can take either
+        # side of the ReLU; one such flip moves dgamma by O(1).  The reference therefore
+        # back-propagates through the kernel's own mask, and the masks must agree
+        # except on those knife-edge elements.
+        mask = (y1.detach() > 0)
+        assert ((pre.detach() > 0) != mask).float().mean().item() < 1e-4
+        y2 = pre * mask.float()
+    else:
+        y2 = pre
+    y2.backward(dy.float())
+
+    assert y1.dtype == torch.bfloat16 and y1.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y1.float(), y2, rtol=2e-2, atol=2e-2)
+    if N * H * W > 1:
+        torch.testing.assert_close(rm, rm2, rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(rv, rv2, rtol=1e-3, atol=1e-3)
+    M = N * H * W
+    tol = dict(rtol=3e-2, atol=3e-2 * max(1.0, M ** 0.5 / 8))
+    torch.testing.assert_close(w1.grad.float(), w2.grad, **tol)
+    torch.testing.assert_close(b1.grad.float(), b2.grad, **tol)
+    # dx: elements whose pre-activation sits within bf16 rounding of 0 may flip the mask
+    diff = (x1.grad.float() - x2.grad).abs()
+    bad = diff > (3e-2 + 3e-2 * x2.grad.abs())
+    assert bad.float().mean().item() < 2e-3, "dx mismatch fraction %.4f" % bad.float().mean().item()
+    if res:
+        d2 = (r1.grad.float() - r2.grad).abs() > (2e-2 + 2e-2 * r2.grad.abs())
+        assert d2.float().mean().item() < 2e-3
+
+
+def test_fused_bn_eval_mode(dev):
+    C = 64
+    m = batchnorm.FusedBatchNormAct(C).to(dev).to(torch.bfloat16)
+    assert m.running_mean.dtype == torch.float32
+    m.running_mean.normal_()
+    m.running_var.uniform_(0.5, 2.0)
+    m.eval()
+    x = torch.randn(4, C, 9, 9, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = m(x)
+    ref = batchnorm.bn_act_reference(x.float(), m.weight.float(), m.bias.float(), None, m.running_mean,
+                                     m.running_var, False, 0.1, 1e-5, True)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_sharded_ps_step_on_gpu_matches_torch_sgd(dev):
+    import copy
+
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec, ShardedPS
+
+    torch.manual_seed(0)
+    m1 = mnist_mlp.build().to(dev)
+    m2 = copy.deepcopy(m1)
+    ps = ShardedPS(list(m1.named_parameters()), opt=OptimizerSpec(kind="momentum", lr=0.1, momentum=0.9),
+                   bucket_mb=0.05, wire_dtype=torch.float32)
+    opt = torch.optim.SGD(m2.parameters(), lr=0.1, momentum=0.9)
+    batch = mnist_mlp.synthetic_batch(64, device=dev, seed=3)
+    for _ in range(5):
+        mnist_mlp.loss_fn(m1, batch).backward()
+        ps.step()
+        opt.zero_grad()
+        mnist_mlp.loss_fn(m2, batch).backward()
+        opt.step()
+    for p, q in zip(m1.parameters(), m2.parameters()):
+        torch.testing.assert_close(p, q, rtol=1e-4, atol=1e-5)
