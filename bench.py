@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--update-mode", default="sync", choices=["sync", "stale"])
     ap.add_argument("--push", default="reduce_scatter", choices=["reduce_scatter", "all_to_all"])
     ap.add_argument("--bucket-mb", type=float, default=32.0)
-    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("DTF_MIOPEN_FIND", "1")),
+    ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("DTF_MIOPEN_FIND", "0")),
                     help="1: let MIOpen benchmark each conv during warm-up (cudnn.benchmark)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("DTF_BENCH_GRAPH", "0")),
                     help="1: capture the whole step in a hipGraph (single GPU only)")
@@ -109,8 +109,13 @@ def main():
         def step():  # noqa: F811
             graph.replay()
             return static_loss
-    for _ in range(a.warmup):
+    t_w = time.perf_counter()
+    for i in range(a.warmup):
         loss = step()
+        if comm.rank == 0 and (i < 3 or a.miopen_find):
+            torch.cuda.synchronize()
+            print("[bench] warmup step %d done at +%.1f s" % (i + 1, time.perf_counter() - t_w), file=sys.stderr,
+                  flush=True)
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
