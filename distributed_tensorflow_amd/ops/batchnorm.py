@@ -26,9 +26,10 @@ def _lib():
     if not _declared:
         P, I, L, Fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
         hip.declare("dtf_bn_partial_floats", [L, I], L)
-        hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, P])
-        hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, L, I, I, P])
-        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, L, I, I, P])
+        hip.declare("dtf_bn_mask_bytes", [L, I], L)
+        hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, P])
+        hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, P, L, I, I, P])
+        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, P])
         _declared = True
     return lib
 
@@ -72,21 +73,26 @@ class _FusedBNAct(torch.autograd.Function):
         dev = x.device
         y = torch.empty_like(x)
         stats = torch.empty(4, C, dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+        mask = None
         if residual is not None:
             assert residual.shape == x.shape and residual.dtype == x.dtype and _nhwc_rows(residual) is not None
+            if relu:
+                mask = torch.empty(int(lib.dtf_bn_mask_bytes(M, C)), dtype=torch.uint8, device=dev)
         rc = lib.dtf_bn_fwd_train(
-            hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
+            hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
             hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
             stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
             hip.ptr(_partial(dev, M, C)), M, C, int(relu), hip.stream())
         hip.check(rc, "dtf_bn_fwd_train")
-        ctx.save_for_backward(x, y if relu else None, weight, stats)
-        ctx.relu, ctx.has_res, ctx.dims = bool(relu), residual is not None, (M, C)
+        ctx.save_for_backward(x, mask, weight, stats)
+        # ReLU mask source for backward: 1 = recompute from x (no residual), 3 = bit mask
+        ctx.relu_mode = 0 if not relu else (3 if residual is not None else 1)
+        ctx.has_res, ctx.dims = residual is not None, (M, C)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, stats = ctx.saved_tensors
+        x, mask, weight, stats = ctx.saved_tensors
         M, C = ctx.dims
         lib = _lib()
         dev = x.device
@@ -97,9 +103,10 @@ class _FusedBNAct(torch.autograd.Function):
         dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
         coef = torch.empty(3, C, dtype=torch.float32, device=dev)
         rc = lib.dtf_bn_bwd_train(
-            hip.ptr(dy), hip.ptr(x), hip.ptr(y), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
-            stats[1].data_ptr(), hip.ptr(dx), hip.ptr(dres), dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef),
-            hip.ptr(_partial(dev, M, C)), M, C, int(ctx.relu), hip.stream())
+            hip.ptr(dy), hip.ptr(x), hip.ptr(mask), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
+            stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), hip.ptr(dres),
+            dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
+            int(ctx.relu_mode), hip.stream())
         hip.check(rc, "dtf_bn_bwd_train")
         return dx, dgb[0], dgb[1], dres, None, None, None, None, None
 
@@ -133,8 +140,10 @@ def fused_bn_act(x, weight, bias, residual=None, running_mean=None, running_var=
     scale = weight.float() * torch.rsqrt(running_var.float() + eps)
     shift = bias.float() - running_mean.float() * scale
     y = torch.empty_like(x)
-    rc = lib.dtf_bn_fwd_apply(hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(scale), hip.ptr(shift), M, C,
-                              int(relu), hip.stream())
+    mask = torch.empty(int(lib.dtf_bn_mask_bytes(M, C)), dtype=torch.uint8, device=x.device) \
+        if (relu and residual is not None) else None
+    rc = lib.dtf_bn_fwd_apply(hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(scale),
+                              hip.ptr(shift), M, C, int(relu), hip.stream())
     hip.check(rc, "dtf_bn_fwd_apply")
     return y
 

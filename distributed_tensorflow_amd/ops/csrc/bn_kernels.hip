@@ -8,8 +8,8 @@
 //
 //   forward   stats   : read x                      (2 B/elem)
 //             apply   : read x (+res), write y      (4-6 B/elem)
-//   backward  reduce  : read dy, x, y               (6 B/elem)
-//             apply   : read dy, x, y, write dx (+dres)   (8-10 B/elem)
+//   backward  reduce  : read dy, x (+1 bit mask)     (4 B/elem)
+//             apply   : read dy, x (+mask), write dx (+dres)   (6-8 B/elem)
 //
 // against ~26-38 B/elem for separate BN / add / ReLU ops.
 //
@@ -26,7 +26,13 @@
 #define BN_ROWS 32        // rows per block iteration
 #define BN_UNROLL 4
 
-enum { BN_FWD_STATS = 0, BN_BWD_RELU = 1, BN_BWD_PLAIN = 2 };
+enum { BN_FWD_STATS = 0, BN_BWD_RELU_X = 1, BN_BWD_PLAIN = 2, BN_BWD_RELU_MASK = 3 };
+// how the backward kernels learn the ReLU mask:
+//   RELU_X    recompute  fma(x, scale, shift) > 0  -- bitwise the forward's own decision,
+//             no extra tensor read (BN+ReLU without residual)
+//   RELU_MASK 1 bit per element written by the forward apply (BN+add+ReLU): 0.125 B/elem
+//             instead of re-reading the 2 B/elem output
+// mask layout: [channel tile][row][8 bytes], byte tx holds the 8 channels of lane tx
 
 __device__ __forceinline__ void ld8bf(const unsigned short* p, float (&v)[8]) {
     u32x4 r = *reinterpret_cast<const u32x4*>(p);
@@ -48,8 +54,10 @@ __device__ __forceinline__ void st8bf(unsigned short* p, const float (&v)[8]) {
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ dy,
-                                                        const unsigned short* __restrict__ y,
+                                                        const unsigned char* __restrict__ mask,
                                                         const float* __restrict__ mean,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
                                                         float* __restrict__ partial, int64_t M, int C,
                                                         int rows_per_block) {
     const int tx = threadIdx.x & 7;
@@ -59,16 +67,22 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    float s1[8], s2[8], mu[8];
+    float s1[8], s2[8], mu[8], sc[8], sh[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; }
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; sc[k] = 0.f; sh[k] = 0.f; }
     if (MODE != BN_FWD_STATS && cvalid) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) mu[k] = mean[c0 + k];
+        if (MODE == BN_BWD_RELU_X) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
+        }
     }
+    const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
     if (cvalid) {
         for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
-            float xv[BN_UNROLL][8], dv[BN_UNROLL][8], yv[BN_UNROLL][8];
+            float xv[BN_UNROLL][8], dv[BN_UNROLL][8];
+            unsigned mb[BN_UNROLL];
             bool ok[BN_UNROLL];
 #pragma unroll
             for (int u = 0; u < BN_UNROLL; ++u) {
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                     const int64_t off = row * C + c0;
                     ld8bf(x + off, xv[u]);
                     if (MODE != BN_FWD_STATS) ld8bf(dy + off, dv[u]);
-                    if (MODE == BN_BWD_RELU) ld8bf(y + off, yv[u]);
+                    if (MODE == BN_BWD_RELU_MASK) mb[u] = mrow[row * 8];
                 }
             }
 #pragma unroll
@@ -91,7 +105,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                         s2[k] = fmaf(xv[u][k], xv[u][k], s2[k]);
                     } else {
                         float d = dv[u][k];
-                        if (MODE == BN_BWD_RELU) d = yv[u][k] > 0.f ? d : 0.f;
+                        if (MODE == BN_BWD_RELU_X) d = fmaf(xv[u][k], sc[k], sh[k]) > 0.f ? d : 0.f;
+                        if (MODE == BN_BWD_RELU_MASK) d = ((mb[u] >> k) & 1u) ? d : 0.f;
                         s1[k] += d;
                         s2[k] = fmaf(d, xv[u][k] - mu[k], s2[k]);
                     }
@@ -206,74 +221,118 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
-// y = [relu]( x*scale[c] + shift[c] [+ res] ); coefficient vectors staged in LDS.
+// y = [relu]( x*scale[c] + shift[c] [+ res] ).  Same [row chunk][channel tile] mapping as the
+// reductions: a lane owns 8 fixed channels, so scale/shift live in registers.
 template <bool RELU, bool RES>
 __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const unsigned short* __restrict__ x,
                                                            const unsigned short* __restrict__ res,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
-                                                           unsigned short* __restrict__ y, int64_t nvec, int C) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* lsc = lds;
-    float* lsh = lds + C;
-    for (int i = threadIdx.x; i < C; i += 256) { lsc[i] = scale[i]; lsh[i] = shift[i]; }
-    __syncthreads();
-    const int cvec = C >> 3;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
-        const int c0 = (int)(v % cvec) << 3;
-        float xv[8], rv[8];
-        ld8bf(x + (v << 3), xv);
-        if (RES) ld8bf(res + (v << 3), rv);
-        const f32x4 sa = *reinterpret_cast<const f32x4*>(lsc + c0), sb = *reinterpret_cast<const f32x4*>(lsc + c0 + 4);
-        const f32x4 ha = *reinterpret_cast<const f32x4*>(lsh + c0), hb = *reinterpret_cast<const f32x4*>(lsh + c0 + 4);
+                                                           unsigned short* __restrict__ y,
+                                                           unsigned char* __restrict__ mask, int64_t M, int C,
+                                                           int rows_per_block) {
+    const int tx = threadIdx.x & 7;
+    const int ty = threadIdx.x >> 3;
+    const int c0 = blockIdx.y * BN_CT + tx * 8;
+    if (c0 >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float sc[8], sh[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float sc = k < 4 ? sa[k] : sb[k - 4], sh = k < 4 ? ha[k] : hb[k - 4];
-            float o = fmaf(xv[k], sc, sh);
-            if (RES) o += rv[k];
-            if (RELU) o = fmaxf(o, 0.f);
-            xv[k] = o;
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
+    unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
+    for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+        float xv[BN_UNROLL][8], rv[BN_UNROLL][8];
+        bool ok[BN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            const int64_t row = r + (int64_t)u * BN_ROWS;
+            ok[u] = row < r1;
+            if (ok[u]) {
+                ld8bf(x + row * C + c0, xv[u]);
+                if (RES) ld8bf(res + row * C + c0, rv[u]);
+            }
         }
-        st8bf(y + (v << 3), xv);
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            if (!ok[u]) continue;
+            const int64_t row = r + (int64_t)u * BN_ROWS;
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float o = fmaf(xv[u][k], sc[k], sh[k]);
+                if (RES) o += rv[u][k];
+                if (RELU) {
+                    m |= (o > 0.f ? 1u : 0u) << k;
+                    o = fmaxf(o, 0.f);
+                }
+                xv[u][k] = o;
+            }
+            st8bf(y + row * C + c0, xv[u]);
+            if (RELU && RES) mrow[row * 8] = (unsigned char)m;
+        }
     }
 }
 
-// dx = k1*dy' + k2*x + k3 ; dres = dy'   (dy' = dy masked by y > 0 when RELU)
-template <bool RELU, bool RES>
+// dx = k1*dy' + k2*x + k3 ; dres = dy'   (dy' = dy under the ReLU mask)
+template <int MODE, bool RES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy,
                                                            const unsigned short* __restrict__ x,
-                                                           const unsigned short* __restrict__ y,
+                                                           const unsigned char* __restrict__ mask,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
                                                            const float* __restrict__ coef,
                                                            unsigned short* __restrict__ dx,
-                                                           unsigned short* __restrict__ dres, int64_t nvec, int C) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    for (int i = threadIdx.x; i < 3 * C; i += 256) lds[i] = coef[i];
-    __syncthreads();
-    const float* l1 = lds;
-    const float* l2 = lds + C;
-    const float* l3 = lds + 2 * C;
-    const int cvec = C >> 3;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
-        const int c0 = (int)(v % cvec) << 3;
-        float dv[8], xv[8], yv[8];
-        ld8bf(dy + (v << 3), dv);
-        ld8bf(x + (v << 3), xv);
-        if (RELU) ld8bf(y + (v << 3), yv);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(l1 + c0), a1 = *reinterpret_cast<const f32x4*>(l1 + c0 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(l2 + c0), b1 = *reinterpret_cast<const f32x4*>(l2 + c0 + 4);
-        const f32x4 d0 = *reinterpret_cast<const f32x4*>(l3 + c0), d1 = *reinterpret_cast<const f32x4*>(l3 + c0 + 4);
+                                                           unsigned short* __restrict__ dres, int64_t M, int C,
+                                                           int rows_per_block) {
+    const int tx = threadIdx.x & 7;
+    const int ty = threadIdx.x >> 3;
+    const int c0 = blockIdx.y * BN_CT + tx * 8;
+    if (c0 >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float k1[8], k2[8], k3[8], sc[8], sh[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float k1 = k < 4 ? a0[k] : a1[k - 4], k2 = k < 4 ? b0[k] : b1[k - 4], k3 = k < 4 ? d0[k] : d1[k - 4];
-            float d = dv[k];
-            if (RELU) d = yv[k] > 0.f ? d : 0.f;
-            dv[k] = d;
-            xv[k] = fmaf(k1, d, fmaf(k2, xv[k], k3));
+    for (int k = 0; k < 8; ++k) {
+        k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k];
+        sc[k] = 0.f; sh[k] = 0.f;
+    }
+    if (MODE == BN_BWD_RELU_X) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
+    }
+    const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
+    for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+        float xv[BN_UNROLL][8], dv[BN_UNROLL][8];
+        unsigned mb[BN_UNROLL];
+        bool ok[BN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            const int64_t row = r + (int64_t)u * BN_ROWS;
+            ok[u] = row < r1;
+            if (ok[u]) {
+                ld8bf(dy + row * C + c0, dv[u]);
+                ld8bf(x + row * C + c0, xv[u]);
+                if (MODE == BN_BWD_RELU_MASK) mb[u] = mrow[row * 8];
+            }
         }
-        st8bf(dx + (v << 3), xv);
-        if (RES) st8bf(dres + (v << 3), dv);
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            if (!ok[u]) continue;
+            const int64_t row = r + (int64_t)u * BN_ROWS;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float d = dv[u][k];
+                if (MODE == BN_BWD_RELU_X) d = fmaf(xv[u][k], sc[k], sh[k]) > 0.f ? d : 0.f;
+                if (MODE == BN_BWD_RELU_MASK) d = ((mb[u] >> k) & 1u) ? d : 0.f;
+                dv[u][k] = d;
+                xv[u][k] = fmaf(k1[k], d, fmaf(k2[k], xv[u][k], k3[k]));
+            }
+            st8bf(dx + row * C + c0, xv[u]);
+            if (RES) st8bf(dres + row * C + c0, dv[u]);
+        }
     }
 }
 
@@ -303,19 +362,36 @@ int64_t dtf_bn_partial_floats(int64_t M, int C) {
     return (int64_t)nb * 2 * C;
 }
 
+// bytes of the ReLU bit mask of an [M, C] tensor (BN + residual + ReLU only)
+int64_t dtf_bn_mask_bytes(int64_t M, int C) { return (int64_t)((C + BN_CT - 1) / BN_CT) * M * 8; }
+
+static void launch_fwd_apply(const void* x, const void* res, void* y, void* mask, const float* scale,
+                             const float* shift, int64_t M, int C, int relu, hipStream_t stream) {
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    const unsigned short *xs = (const unsigned short*)x, *rs = (const unsigned short*)res;
+    unsigned short* ys = (unsigned short*)y;
+    unsigned char* ms = (unsigned char*)mask;
+#define FWD(R, S) hipLaunchKernelGGL((bn_fwd_apply_kernel<R, S>), dim3(nb, ct), dim3(256), 0, stream, xs, rs, scale, shift, ys, ms, M, C, rpb)
+    if (relu) { if (res) FWD(true, true); else FWD(true, false); }
+    else { if (res) FWD(false, true); else FWD(false, false); }
+#undef FWD
+}
+
 // Training forward.  x,y,res: bf16 [M,C]; gamma/beta: param dtype; running_*: fp32 or null;
-// mean/invstd/scale/shift: fp32 [C] outputs; partial: workspace.
-int dtf_bn_fwd_train(const void* x, const void* res, void* y, const void* gamma, const void* beta, int param_dtype,
-                     float* running_mean, float* running_var, float momentum, float eps, float* mean,
-                     float* invstd, float* scale, float* shift, float* partial, int64_t M, int C, int relu,
-                     hipStream_t stream) {
+// stats outputs mean/invstd/scale/shift: fp32 [C]; partial: workspace; mask: dtf_bn_mask_bytes
+// (only written when relu && res).
+int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const void* gamma, const void* beta,
+                     int param_dtype, float* running_mean, float* running_var, float momentum, float eps,
+                     float* mean, float* invstd, float* scale, float* shift, float* partial, int64_t M, int C,
+                     int relu, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (C % 8 != 0 || M <= 0) return -20;
-    if (2 * C * sizeof(float) > 64 * 1024) return -21;
+    if (relu && res && !mask) return -22;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
     hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS>), dim3(nb, ct), dim3(256), 0, stream,
-                       (const unsigned short*)x, nullptr, nullptr, nullptr, partial, M, C, rpb);
+                       (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, nullptr, partial, M, C, rpb);
     const float inv_count = 1.0f / (float)M;
     const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
     const int fgrid = (C + 15) / 16;
@@ -327,55 +403,41 @@ int dtf_bn_fwd_train(const void* x, const void* res, void* y, const void* gamma,
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
                            inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
                            scale, shift);
-    const int64_t nvec = M * C / 8;
-    const int grid = dtf_stream_grid(nvec, 256);
-    const size_t lds = 2 * C * sizeof(float);
-    const unsigned short *xs = (const unsigned short*)x, *rs = (const unsigned short*)res;
-    unsigned short* ys = (unsigned short*)y;
-#define FWD(R, S) hipLaunchKernelGGL((bn_fwd_apply_kernel<R, S>), dim3(grid), dim3(256), lds, stream, xs, rs, scale, shift, ys, nvec, C)
-    if (relu) { if (res) FWD(true, true); else FWD(true, false); }
-    else { if (res) FWD(false, true); else FWD(false, false); }
-#undef FWD
+    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }
 
 // Inference / frozen-statistics forward: scale/shift precomputed by the caller.
-int dtf_bn_fwd_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, int64_t M,
-                     int C, int relu, hipStream_t stream) {
+int dtf_bn_fwd_apply(const void* x, const void* res, void* y, void* mask, const float* scale, const float* shift,
+                     int64_t M, int C, int relu, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (C % 8 != 0 || M <= 0) return -20;
-    if (2 * C * sizeof(float) > 64 * 1024) return -21;
-    const int64_t nvec = M * C / 8;
-    const int grid = dtf_stream_grid(nvec, 256);
-    const size_t lds = 2 * C * sizeof(float);
-    const unsigned short *xs = (const unsigned short*)x, *rs = (const unsigned short*)res;
-    unsigned short* ys = (unsigned short*)y;
-#define FWD(R, S) hipLaunchKernelGGL((bn_fwd_apply_kernel<R, S>), dim3(grid), dim3(256), lds, stream, xs, rs, scale, shift, ys, nvec, C)
-    if (relu) { if (res) FWD(true, true); else FWD(true, false); }
-    else { if (res) FWD(false, true); else FWD(false, false); }
-#undef FWD
+    if (relu && res && !mask) return -22;
+    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }
 
-// Training backward.  dres may be null (no residual branch).  coef: fp32 [3*C] workspace.
-int dtf_bn_bwd_train(const void* dy, const void* x, const void* y, const void* gamma, int param_dtype,
-                     const float* mean, const float* invstd, void* dx, void* dres, void* dgamma, void* dbeta,
-                     float* coef, float* partial, int64_t M, int C, int relu, hipStream_t stream) {
+// Training backward.  relu_mode: 0 none, 1 ReLU without residual (mask recomputed from x,
+// scale, shift), 3 ReLU after residual add (bit mask from the forward).  dres may be null.
+// coef: fp32 [3*C] workspace.
+int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void* gamma, int param_dtype,
+                     const float* mean, const float* invstd, const float* scale, const float* shift, void* dx,
+                     void* dres, void* dgamma, void* dbeta, float* coef, float* partial, int64_t M, int C,
+                     int relu_mode, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (C % 8 != 0 || M <= 0) return -20;
-    if (3 * C * sizeof(float) > 64 * 1024) return -21;
+    if (relu_mode == BN_BWD_RELU_MASK && !mask) return -22;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
-    const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x,
-                         *ys = (const unsigned short*)y;
-    if (relu)
-        hipLaunchKernelGGL((bn_reduce_kernel<BN_BWD_RELU>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ys, mean,
-                           partial, M, C, rpb);
-    else
-        hipLaunchKernelGGL((bn_reduce_kernel<BN_BWD_PLAIN>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ys, mean,
-                           partial, M, C, rpb);
+    const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x;
+    const unsigned char* ms = (const unsigned char*)mask;
+#define RED(MODE) hipLaunchKernelGGL((bn_reduce_kernel<MODE>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, rpb)
+    if (relu_mode == BN_BWD_RELU_X) RED(BN_BWD_RELU_X);
+    else if (relu_mode == BN_BWD_RELU_MASK) RED(BN_BWD_RELU_MASK);
+    else RED(BN_BWD_PLAIN);
+#undef RED
     const float inv_count = 1.0f / (float)M;
     const int fgrid = (C + 15) / 16;
     if (param_dtype == DTF_BF16)
@@ -384,13 +446,11 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* y, const void* g
     else
         hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
                            inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
-    const int64_t nvec = M * C / 8;
-    const int grid = dtf_stream_grid(nvec, 256);
-    const size_t lds = 3 * C * sizeof(float);
     unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
-#define BWD(R, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<R, S>), dim3(grid), dim3(256), lds, stream, dys, xs, ys, coef, dxs, drs, nvec, C)
-    if (relu) { if (dres) BWD(true, true); else BWD(true, false); }
-    else { if (dres) BWD(false, true); else BWD(false, false); }
+#define BWD(MODE, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<MODE, S>), dim3(nb, ct), dim3(256), 0, stream, dys, xs, ms, scale, shift, coef, dxs, drs, M, C, rpb)
+    if (relu_mode == BN_BWD_RELU_X) { if (dres) BWD(BN_BWD_RELU_X, true); else BWD(BN_BWD_RELU_X, false); }
+    else if (relu_mode == BN_BWD_RELU_MASK) { if (dres) BWD(BN_BWD_RELU_MASK, true); else BWD(BN_BWD_RELU_MASK, false); }
+    else { if (dres) BWD(BN_BWD_PLAIN, true); else BWD(BN_BWD_PLAIN, false); }
 #undef BWD
     DTF_CHECK_LAUNCH();
     return 0;
