@@ -1,0 +1,128 @@
+"""Wide&Deep CTR model with large row-sharded embedding tables (config #3; the
+embedding scatter-add path of the north star).
+
+* categorical features -> ONE fused, row-sharded table space
+  (:class:`~distributed_tensorflow_amd.parallel.embedding.ShardedEmbedding`): each row holds the
+  ``embedding_dim`` deep vector plus (padded to 8) the scalar *wide* weight of that id, so
+  a step needs one id exchange, one K3 gather and one K4 sparse apply for wide and deep
+  together;
+* deep tower: concat(embeddings, dense features) -> 1024 -> 512 -> 256 -> 1 (dense
+  variables, PS-sharded through the ordinary push/pull buckets);
+* wide part: sum of the ids' wide weights + a linear layer on the dense features.
+
+TF names (``tf.estimator.DNNLinearCombinedClassifier`` conventions):
+``dnn/hiddenlayer_0/kernel``, ``dnn/logits/bias``, ``linear/linear_model/dense/weights``,
+``embeddings/part_<k>`` for the partitioned table.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..parallel.comm import Comm
+from ..parallel.embedding import ShardedEmbedding
+
+NEEDS_COMM = True
+WIDE_PAD = 8
+
+
+class WideDeep(nn.Module):
+    def __init__(self, comm=None, device=None, num_features=26, rows_per_table=100000, embedding_dim=64,
+                 dense_features=13, hidden=(1024, 512, 256), emb_optimizer="adagrad", emb_lr=0.05, atomic=False):
+        super().__init__()
+        comm = comm or Comm.single()
+        if isinstance(rows_per_table, (list, tuple)):
+            rows = [int(r) for r in rows_per_table]
+        else:
+            rows = [int(rows_per_table)] * int(num_features)
+        self.num_features, self.embedding_dim = len(rows), int(embedding_dim)
+        self.dense_features = int(dense_features)
+        self.embeddings = ShardedEmbedding(rows, self.embedding_dim + WIDE_PAD, comm, device, optimizer=emb_optimizer,
+                                           lr=emb_lr, atomic=atomic,
+                                           names=["C%d" % (i + 1) for i in range(len(rows))])
+        self.embeddings.grad_scale = 1.0 / comm.world_size
+        dims = [self.num_features * self.embedding_dim + self.dense_features] + list(hidden)
+        self.hidden = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.logits = nn.Linear(dims[-1], 1)
+        self.wide_dense = nn.Linear(self.dense_features, 1)
+
+    def forward(self, ids, dense):
+        e = self.embeddings(ids)                                   # [B, F, D + 8]
+        deep = e[:, :, :self.embedding_dim].reshape(ids.shape[0], -1)
+        wide = e[:, :, self.embedding_dim].float().sum(1, keepdim=True)
+        h = torch.cat([deep, dense.to(deep.dtype)], 1)
+        for lin in self.hidden:
+            h = F.relu(lin(h))
+        return self.logits(h).float() + wide + self.wide_dense(dense.to(deep.dtype)).float()
+
+
+def build(comm=None, device=None, **kw):
+    allowed = ("num_features", "rows_per_table", "embedding_dim", "dense_features", "emb_optimizer", "emb_lr", "atomic")
+    args = {}
+    for k in allowed:
+        if k in kw:
+            v = kw[k]
+            if k in ("num_features", "rows_per_table", "embedding_dim", "dense_features"):
+                v = int(v)
+            elif k == "emb_lr":
+                v = float(v)
+            elif k == "atomic":
+                v = str(v).lower() in ("1", "true")
+            args[k] = v
+    return WideDeep(comm, device, **args)
+
+
+def prepare(model, device):
+    device = torch.device(device)
+    emb = model.embeddings
+    model = model.to(device)
+    if device.type == "cuda":
+        # dense tower in bf16; tables and accumulators stay fp32
+        tab, acc, off = emb.table, emb.accumulator, emb.table_offsets
+        model = model.to(torch.bfloat16)
+        emb.table, emb.accumulator, emb.table_offsets = tab.float(), (acc.float() if acc is not None else None), off
+        emb._anchor.data = emb._anchor.data.float()
+    return model
+
+
+def tf_variable_names(model):
+    out = {}
+    for n, _ in model.named_parameters():
+        p = n.split(".")
+        if p[0] == "hidden":
+            out[n] = "dnn/hiddenlayer_%s/%s" % (p[1], "kernel" if p[2] == "weight" else "bias")
+        elif p[0] == "logits":
+            out[n] = "dnn/logits/" + ("kernel" if p[1] == "weight" else "bias")
+        elif p[0] == "wide_dense":
+            out[n] = "linear/linear_model/dense/" + ("weights" if p[1] == "weight" else "bias_weights")
+    return out
+
+
+def synthetic_batch(batch, device="cpu", seed=None, model=None, num_features=26, rows_per_table=100000,
+                    dense_features=13, **_):
+    """Zipf-skewed ids (duplicates inside a batch, like real CTR logs) + a label that
+    depends on a few ids so the loss can fall."""
+    device = torch.device(device)
+    if model is not None:
+        rows = model.embeddings.table_rows
+        dense_features = model.dense_features
+    else:
+        rows = [int(rows_per_table)] * int(num_features)
+    g = torch.Generator().manual_seed(seed) if seed is not None else None
+    u = torch.rand(batch, len(rows), generator=g)
+    r = torch.tensor(rows, dtype=torch.float32).unsqueeze(0)
+    ids = (r * u.pow(3.0)).long().clamp_(min=0)            # cubic skew: small ids are hot
+    ids = torch.minimum(ids, (r - 1).long())
+    dense = torch.randn(batch, dense_features, generator=g)
+    y = ((ids[:, 0] % 2 == 0) ^ (dense[:, 0] > 0)).float()
+    return ids.to(device), dense.to(device), y.to(device)
+
+
+def loss_fn(model, batch):
+    ids, dense, y = batch
+    return F.binary_cross_entropy_with_logits(model(ids, dense).squeeze(1), y)
+
+
+def default_optimizer():
+    from ..parallel.ps_runtime import OptimizerSpec
+
+    return OptimizerSpec(kind="adam", lr=1e-3, adamw=False, weight_decay=0.0)

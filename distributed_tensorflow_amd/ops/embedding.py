@@ -1,0 +1,156 @@
+"""Embedding lookup and sparse gradient apply (kernels K3 / K4).
+
+Replaces TF1's ``embedding_lookup`` (``Gather`` on a PS-hosted partitioned
+variable) and ``ScatterAdd`` / ``SparseApplyAdagrad`` on the PS (externals
+X3/X4).  ``*_reference`` are the PyTorch definitions (CPU path + test oracle).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import hip
+
+SGD, ADAGRAD, ROWWISE_ADAGRAD = 0, 1, 2
+_OPT = {"sgd": SGD, "adagrad": ADAGRAD, "rowwise_adagrad": ROWWISE_ADAGRAD}
+_declared = False
+
+
+def _lib():
+    global _declared
+    lib = hip.lib()
+    if not _declared:
+        P, I, L, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+        hip.declare("dtf_embedding_gather", [P, I, P, P, I, L, I, I, L, F, P])
+        hip.declare("dtf_embedding_sparse_apply", [P, I, P, P, I, P, P, P, P, P, P, P, L, I, I, L, I, F, F, F, F, P])
+        hip.declare("dtf_embedding_sgd_atomic", [P, P, P, I, L, I, I, L, F, F, P])
+        hip.declare("dtf_embedding_chunk_rows", [])
+        _declared = True
+    return lib
+
+
+# ---------------------------------------------------------------------------
+# K3
+# ---------------------------------------------------------------------------
+
+def gather_reference(table, idx, out_dtype=None, bag=1, mean=False):
+    R, D = table.shape
+    idx = idx.reshape(-1)
+    valid = (idx >= 0) & (idx < R)
+    rows = table[idx.clamp(0, R - 1)].float() * valid.unsqueeze(1)
+    out = rows.view(-1, bag, D).sum(1)
+    if mean:
+        out = out / bag
+    return out.to(out_dtype or table.dtype)
+
+
+def embedding_gather(table, idx, out_dtype=None, bag=1, mean=False):
+    """``out[b] = sum_j table[idx[b*bag + j]]`` -> ``[idx.numel() // bag, D]``.
+    Ids outside ``[0, R)`` are padding and contribute zeros."""
+    out_dtype = out_dtype or table.dtype
+    if not table.is_cuda:
+        return gather_reference(table, idx, out_dtype, bag, mean)
+    assert table.dim() == 2 and table.is_contiguous() and idx.dtype == torch.int64
+    idx = idx.reshape(-1).contiguous()
+    assert idx.numel() % bag == 0
+    R, D = table.shape
+    nb = idx.numel() // bag
+    out = torch.empty(nb, D, dtype=out_dtype, device=table.device)
+    rc = _lib().dtf_embedding_gather(hip.ptr(table), hip.dt(table), hip.ptr(idx), hip.ptr(out), hip.dt(out), nb,
+                                     int(bag), D, R, 1.0 / bag if mean else 1.0, hip.stream())
+    hip.check(rc, "dtf_embedding_gather")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# K4
+# ---------------------------------------------------------------------------
+
+def sparse_apply_reference(table, acc, idx, grad, opt="sgd", lr=0.01, eps=1e-10, grad_scale=1.0, wd=0.0, bag=1):
+    """Sum the gradients of duplicate ids, then one optimizer step per unique row."""
+    R, D = table.shape
+    idx = idx.reshape(-1)
+    g_rows = grad.float().repeat_interleave(bag, 0) if bag > 1 else grad.float()
+    valid = (idx >= 0) & (idx < R)
+    idx, g_rows = idx[valid], g_rows[valid]
+    uniq, inv = torch.unique(idx, return_inverse=True)
+    g = torch.zeros(uniq.numel(), D, dtype=torch.float32, device=table.device).index_add_(0, inv, g_rows)
+    w = table[uniq].float()
+    g = g * grad_scale + wd * w
+    if opt == "sgd":
+        w = w - lr * g
+    elif opt == "adagrad":
+        h = acc[uniq] + g * g
+        acc[uniq] = h
+        w = w - lr * g * torch.rsqrt(h + eps)
+    else:
+        h = acc[uniq] + (g * g).mean(1)
+        acc[uniq] = h
+        w = w - lr * g * torch.rsqrt(h + eps).unsqueeze(1)
+    table[uniq] = w.to(table.dtype)
+
+
+def segment_plan(idx, chunk):
+    """Sort ids and describe their runs with fixed-size tensors (no host sync):
+    ``sorted_ids, perm, chunk_begin[n+1], seg_begin[n+1], seg_first_chunk[n+1], nchunks[1]``."""
+    n = idx.numel()
+    dev = idx.device
+    sid, perm = torch.sort(idx.reshape(-1), stable=True)
+    pos = torch.arange(n, device=dev)
+    head = torch.ones(n, dtype=torch.bool, device=dev)
+    head[1:] = sid[1:] != sid[:-1]
+    seg_start_of = torch.cummax(torch.where(head, pos, torch.zeros_like(pos)), 0).values
+    chead = ((pos - seg_start_of) % chunk) == 0
+    chunk_id = torch.cumsum(chead, 0) - 1
+    seg_id = torch.cumsum(head, 0) - 1
+    big = torch.full((n + 1,), n, dtype=torch.int64, device=dev)
+    chunk_begin = big.clone().scatter_reduce_(0, chunk_id, pos, "amin")
+    seg_begin = big.clone().scatter_reduce_(0, seg_id, pos, "amin")
+    seg_first_chunk = big.clone().scatter_reduce_(0, seg_id, chunk_id, "amin")
+    nchunks = (chunk_id[-1:] + 1).contiguous()
+    return sid, perm, chunk_begin, seg_begin, seg_first_chunk, nchunks
+
+
+_ws = {}
+
+
+def _workspace(device, numel):
+    w = _ws.get(device)
+    if w is None or w.numel() < numel:
+        w = torch.empty(max(numel, 1 << 20), dtype=torch.float32, device=device)
+        _ws[device] = w
+    return w
+
+
+def embedding_sparse_apply(table, acc, idx, grad, opt="sgd", lr=0.01, eps=1e-10, grad_scale=1.0, wd=0.0, bag=1,
+                           atomic=False):
+    """In-place sparse optimizer step on the rows ``idx`` of ``table``.
+
+    ``grad`` is ``[idx.numel() // bag, D]`` (the gradient of the gather output).
+    ``atomic=True`` selects the float-atomic form (SGD, fp32 table, ``wd == 0``)."""
+    if not table.is_cuda:
+        return sparse_apply_reference(table, acc, idx, grad, opt, lr, eps, grad_scale, wd, bag)
+    lib = _lib()
+    idx = idx.reshape(-1).contiguous()
+    n = idx.numel()
+    if n == 0:
+        return
+    R, D = table.shape
+    assert grad.is_contiguous() and grad.shape == (n // bag, D) and idx.dtype == torch.int64
+    if atomic:
+        assert opt == "sgd" and table.dtype == torch.float32 and wd == 0.0
+        rc = lib.dtf_embedding_sgd_atomic(hip.ptr(table), hip.ptr(idx), hip.ptr(grad), hip.dt(grad), n, D, int(bag), R,
+                                          float(lr), float(grad_scale), hip.stream())
+        hip.check(rc, "dtf_embedding_sgd_atomic")
+        return
+    chunk = int(lib.dtf_embedding_chunk_rows())
+    sid, perm, chunk_begin, seg_begin, seg_first_chunk, nchunks = segment_plan(idx, chunk)
+    partial = _workspace(table.device, n * D)
+    rc = lib.dtf_embedding_sparse_apply(
+        hip.ptr(table), hip.dt(table), hip.ptr(acc), hip.ptr(grad), hip.dt(grad), hip.ptr(sid), hip.ptr(perm),
+        hip.ptr(chunk_begin), hip.ptr(seg_begin), hip.ptr(seg_first_chunk), hip.ptr(nchunks), hip.ptr(partial),
+        n, D, int(bag), R, _OPT[opt], float(lr), float(eps), float(grad_scale), float(wd), hip.stream())
+    if rc == -31:
+        raise ValueError("rowwise_adagrad needs D/8 to divide 64 (D in 8,16,32,...,512)")
+    hip.check(rc, "dtf_embedding_sparse_apply")

@@ -29,7 +29,7 @@ from ..ops import bucket as bucket_ops
 from ..ops import optim as optim_ops
 from .comm import Comm
 from .layout import FlatLayout
-from .ps_runtime import OptimizerSpec
+from .ps_runtime import OptimizerSpec, trainable
 
 PUSH, DONE = 0.0, 1.0
 
@@ -140,7 +140,7 @@ class PSWorkerClient(_Base):
 
     def __init__(self, named_params, comm, num_ps, opt=None, bucket_mb=32.0, wire_dtype=torch.float32,
                  update_mode="sync"):
-        self.named_params = [(n, p) for n, p in named_params if p.requires_grad]
+        self.named_params = trainable(named_params)
         self.params = [p for _, p in self.named_params]
         dev = self.params[0].device
         super().__init__([(n, p.numel()) for n, p in self.named_params], comm, num_ps, opt, bucket_mb,

@@ -64,13 +64,19 @@ class OptimizerSpec:
         return ()
 
 
+def trainable(named_params):
+    """Dense variables that go through the PS buckets: trainable parameters, minus the ones a
+    module manages itself (``dtf_skip_ps``, e.g. the autograd anchor of ShardedEmbedding)."""
+    return [(n, p) for n, p in named_params if p.requires_grad and not getattr(p, "dtf_skip_ps", False)]
+
+
 class ShardedPS:
     def __init__(self, named_params, comm: Comm = None, opt: OptimizerSpec = None, bucket_mb=32.0,
                  wire_dtype=None, update_mode="sync", push="reduce_scatter", overlap=True,
                  broadcast_init=True):
         self.comm = comm or Comm.single()
         self.opt = opt or OptimizerSpec()
-        self.named_params = [(n, p) for n, p in named_params if p.requires_grad]
+        self.named_params = trainable(named_params)
         assert self.named_params, "no trainable parameters"
         self.params = [p for _, p in self.named_params]
         self.device = self.params[0].device

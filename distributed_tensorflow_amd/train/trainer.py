@@ -61,8 +61,10 @@ def _inject(fault, worker, step):
             raise RuntimeError("injected fault")
 
 
-def prepare_model(mod, opts, device):
+def prepare_model(mod, opts, device, comm=None):
     kw = dict(opts.extra)
+    if getattr(mod, "NEEDS_COMM", False):
+        kw.update(comm=comm, device=device)
     model = mod.build(**kw)
     if hasattr(mod, "prepare"):
         model = mod.prepare(model, device)
@@ -71,11 +73,30 @@ def prepare_model(mod, opts, device):
     return model
 
 
+def _embedding_modules(model):
+    from ..parallel.embedding import ShardedEmbedding
+
+    return [(n, m) for n, m in model.named_modules() if isinstance(m, ShardedEmbedding)]
+
+
 def replicated_state(model, ps):
+    """Non-PS state saved by the chief: global_step and BatchNorm moving statistics (sharded
+    embedding tables are NOT replicated state: every rank writes its own part)."""
+    skip = tuple(n + "." for n, _ in _embedding_modules(model))
     rep = {"global_step": torch.tensor(ps.global_step, dtype=torch.int64)}
     for n, b in model.named_buffers():
-        rep[n] = b
+        if not n.startswith(skip) if skip else True:
+            rep[n] = b
     return rep
+
+
+def save_checkpoint(model, ps, export, step, tf_names, chief):
+    sections, variables = {}, {}
+    for _, m in _embedding_modules(model):
+        sections.update(m.checkpoint_sections())
+        variables.update(m.checkpoint_variables())
+    return ckpt.save_ps(ps, export, step, tf_names, replicated_state(model, ps) if chief else None,
+                        extra_sections=sections or None, extra_variables=variables or None)
 
 
 def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=None, on_step=None,
@@ -128,7 +149,9 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
 
         with torch.device("meta"):
             meta_model = mod.build(**opts.extra)
-        shapes = [(n, p.numel()) for n, p in meta_model.named_parameters() if p.requires_grad]
+        from ..parallel.ps_runtime import trainable
+
+        shapes = [(n, p.numel()) for n, p in trainable(meta_model.named_parameters())]
         srv = PSServer(shapes, comm, num_ps, opt, opts.bucket_mb, wire, device,
                        "async" if opts.update_mode in ("async", "stale") else "sync")
         print("[ps %d] serving shard of %d elements (%s)" % (task_index, srv.layout.shard_total,
@@ -147,7 +170,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
         return 0
 
     # ------------------------------------------------------------ worker task
-    model = prepare_model(mod, opts, device)
+    model = prepare_model(mod, opts, device, comm)
     named = list(model.named_parameters())
     if placement == "dedicated":
         from ..parallel.dedicated_ps import PSWorkerClient
@@ -169,8 +192,10 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
                     b.copy_(rep[n])
         start_step = rd.step
         print("[worker %d] resumed from step %d" % (task_index, start_step), flush=True)
-    batch = mod.synthetic_batch(opts.batch, device=device, seed=opts.seed + 1 + task_index,
-                                **{k: v for k, v in opts.extra.items() if k in ("seq_len",)})
+    bkw = {k: int(v) for k, v in opts.extra.items() if k in ("seq_len", "image_size")}
+    if getattr(mod, "NEEDS_COMM", False):
+        bkw["model"] = model
+    batch = mod.synthetic_batch(opts.batch, device=device, seed=opts.seed + 1 + task_index, **bkw)
     fault = _parse_fault(opts.fault)
     first = {"done": False}
 
@@ -184,7 +209,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
                 metrics(t_step1=now, first_loss=float(loss.detach().float().item()))
                 print("[worker 0] first step done %.3f s after task start" % (now - t_start), flush=True)
         if opts.ckpt_every and do_ckpt and step % opts.ckpt_every == 0 and placement != "dedicated":
-            ckpt.save_ps(ps, export, step, tf_names, replicated_state(model, ps) if chief else None)
+            save_checkpoint(model, ps, export, step, tf_names, chief)
 
     remaining = max(0, opts.steps - start_step)
     items = opts.batch * num_workers
@@ -200,7 +225,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
             variables = ckpt.dense_variable_index(ps.layout, tf_names, shapes, opt.slots)
             ckpt.write_index(export, opts.steps, num_ps, variables, extra={"optimizer": opt.kind})
     elif do_ckpt:
-        ckpt.save_ps(ps, export, ps.global_step, tf_names, replicated_state(model, ps) if chief else None)
+        save_checkpoint(model, ps, export, ps.global_step, tf_names, chief)
     if chief:
         metrics(t_done=time.time(), step=ps.global_step, items_per_sec=rate,
                 final_loss=last if last is not None else "nan")

@@ -14,10 +14,52 @@ from distributed_tensorflow_amd.parallel.comm import Comm  # noqa: E402
 from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec, ShardedPS  # noqa: E402
 
 
+def widedeep_case(comm, out_dir):
+    """Row-sharded embeddings over W ranks == the same model on one rank with the whole batch."""
+    from distributed_tensorflow_amd.models import wide_deep as wd
+
+    r, W = comm.rank, comm.world_size
+    torch.manual_seed(5)
+    kw = dict(num_features=4, rows_per_table=97, embedding_dim=8, emb_optimizer="adagrad", emb_lr=0.1)
+    model = wd.build(comm=comm, device="cpu", **kw)
+    # W-independent table init: the same global rows everywhere
+    g = torch.Generator().manual_seed(99)
+    rows = torch.arange(model.embeddings.total_rows)
+    vals = torch.randn(model.embeddings.total_rows, model.embeddings.dim, generator=g) * 0.05
+    model.embeddings.load_rows(rows, vals)
+    ps = ShardedPS(list(model.named_parameters()), comm, OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9),
+                   bucket_mb=0.01, wire_dtype=torch.float32)
+    ids, dense, y = wd.synthetic_batch(64, seed=21, model=model)
+    per = 64 // W
+    sl = slice(r * per, (r + 1) * per)
+    batch = (ids[sl], dense[sl], y[sl])
+    losses = []
+    for _ in range(5):
+        loss = wd.loss_fn(model, batch)
+        loss.backward()
+        ps.step()
+        losses.append(float(loss.detach()))
+    # reassemble the full table on every rank
+    full = torch.zeros(model.embeddings.total_rows, model.embeddings.dim)
+    mine = torch.arange(r, model.embeddings.total_rows, W)
+    full[mine] = model.embeddings.table
+    import torch.distributed as dist
+    if W > 1:
+        dist.all_reduce(full)
+    dense_full = ps.full_master()
+    if r == 0:
+        torch.save({"table": full, "dense": dense_full, "losses": losses},
+                   os.path.join(out_dir, "result_widedeep_w%d.pt" % W))
+    comm.barrier()
+    comm.close()
+
+
 def main():
     case, out_dir = sys.argv[1], sys.argv[2]
     comm = Comm.from_env(torch.device("cpu"), backend="gloo")
     r, W = comm.rank, comm.world_size
+    if case == "widedeep":
+        return widedeep_case(comm, out_dir)
     torch.manual_seed(7)   # same init everywhere; broadcast_init also enforces it
     model = mnist_mlp.build()
     kind = "adam" if "adam" in case else "momentum"

@@ -101,3 +101,13 @@ def test_checkpoint_resharding_2_to_4_ranks(tmp_path):
     resumed = run_ranks(4, "resume_momentum", tmp_path)
     for n, p in full["params"].items():
         torch.testing.assert_close(resumed["params"][n], p, rtol=1e-5, atol=1e-6)
+
+
+def test_sharded_embedding_equals_single_rank(tmp_path):
+    """Config #3 plumbing: ids all-to-all -> owner gather -> rows all-to-all; backward:
+    row grads all-to-all -> sort/segment sparse Adagrad on the owner."""
+    one = run_ranks(1, "widedeep", tmp_path)
+    two = run_ranks(2, "widedeep", tmp_path)
+    torch.testing.assert_close(two["table"], one["table"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(two["dense"][: one["dense"].numel()].sum(), one["dense"].sum(), rtol=1e-3, atol=1e-3)
+    assert one["losses"][-1] < one["losses"][0]

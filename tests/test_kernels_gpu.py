@@ -213,3 +213,86 @@ def test_sharded_ps_step_on_gpu_matches_torch_sgd(dev):
         opt.step()
     for p, q in zip(m1.parameters(), m2.parameters()):
         torch.testing.assert_close(p, q, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------
+# K3 / K4 embeddings
+# ---------------------------------------------------------------------------
+from distributed_tensorflow_amd.ops import embedding as emb  # noqa: E402
+
+
+@pytest.mark.parametrize("D,tdt,odt", [(64, torch.float32, torch.bfloat16), (128, torch.bfloat16, torch.bfloat16),
+                                       (16, torch.float32, torch.float32), (1, torch.float32, torch.float32),
+                                       (72, torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("bag", [1, 4])
+def test_embedding_gather(dev, D, tdt, odt, bag):
+    torch.manual_seed(0)
+    R = 10007
+    table = torch.randn(R, D, device=dev).to(tdt)
+    idx = torch.randint(-2, R + 2, (4096 * bag,), device=dev)      # includes padding ids
+    out = emb.embedding_gather(table, idx, odt, bag, mean=(bag > 1))
+    ref = emb.gather_reference(table, idx, odt, bag, mean=(bag > 1))
+    torch.testing.assert_close(out.float(), ref.float(), rtol=1e-2 if odt == torch.bfloat16 else 1e-6, atol=1e-2 if odt == torch.bfloat16 else 1e-6)
+
+
+def _skewed_ids(n, R, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.rand(n, generator=g)
+    ids = (R * u.pow(4.0)).long().clamp_(0, R - 1)
+    ids[: n // 8] = 3                      # one very hot id: exercises the chunk splitting
+    ids[-5:] = -1                          # padding
+    return ids[torch.randperm(n, generator=g)].to(dev)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adagrad", "rowwise_adagrad"])
+@pytest.mark.parametrize("D,gdt", [(64, torch.bfloat16), (16, torch.float32), (1, torch.float32)])
+def test_embedding_sparse_apply_deterministic(dev, opt, D, gdt):
+    if opt == "rowwise_adagrad" and D == 1:
+        pytest.skip("row-wise needs D % 8 == 0")
+    R, n = 5000, 20000
+    torch.manual_seed(1)
+    table = torch.randn(R, D, device=dev)
+    acc = None if opt == "sgd" else torch.full((R, D) if opt == "adagrad" else (R,), 0.1, device=dev)
+    idx = _skewed_ids(n, R, dev, 2)
+    grad = torch.randn(n, D, device=dev).to(gdt)
+    t1, a1 = table.clone(), None if acc is None else acc.clone()
+    t2, a2 = table.clone(), None if acc is None else acc.clone()
+    kw = dict(opt=opt, lr=0.05, eps=1e-8, grad_scale=0.5)
+    emb.embedding_sparse_apply(t1, a1, idx, grad, **kw)
+    emb.sparse_apply_reference(t2, a2, idx, grad, **kw)
+    torch.testing.assert_close(t1, t2, rtol=2e-4, atol=2e-4)
+    if acc is not None:
+        torch.testing.assert_close(a1, a2, rtol=2e-4, atol=1e-4)
+    # bitwise reproducible
+    t3, a3 = table.clone(), None if acc is None else acc.clone()
+    emb.embedding_sparse_apply(t3, a3, idx, grad, **kw)
+    assert torch.equal(t1, t3)
+
+
+def test_embedding_sgd_atomic(dev):
+    R, n, D = 3000, 50000, 64
+    torch.manual_seed(3)
+    table = torch.randn(R, D, device=dev)
+    idx = _skewed_ids(n, R, dev, 4)
+    grad = torch.randn(n, D, device=dev).to(torch.bfloat16)
+    t1, t2 = table.clone(), table.clone()
+    emb.embedding_sparse_apply(t1, None, idx, grad, opt="sgd", lr=0.01, atomic=True)
+    emb.sparse_apply_reference(t2, None, idx, grad, opt="sgd", lr=0.01)
+    torch.testing.assert_close(t1, t2, rtol=1e-3, atol=2e-3)
+
+
+def test_wide_deep_trains_on_gpu(dev):
+    from distributed_tensorflow_amd.models import wide_deep as wd
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+
+    torch.manual_seed(0)
+    m = wd.prepare(wd.build(device=dev, num_features=8, rows_per_table=2000, embedding_dim=32), dev)
+    ps = ShardedPS(list(m.named_parameters()), opt=wd.default_optimizer())
+    b = wd.synthetic_batch(2048, device=dev, seed=1, model=m)
+    losses = []
+    for _ in range(40):
+        loss = wd.loss_fn(m, b)
+        loss.backward()
+        ps.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.6 * losses[0], losses[::8]
