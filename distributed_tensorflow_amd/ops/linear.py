@@ -1,0 +1,148 @@
+"""Fused Linear + bias + activation (+ residual) (kernel K6; replaces TF's
+``MatMul + BiasAdd + Relu/Gelu`` on the worker).
+
+Forward is the hand-written gfx950 MFMA GEMM of ``csrc/gemm_kernels.hip`` with the whole
+epilogue fused; backward computes ``dZ = dY * act'(Z)`` and the bias gradient in one
+hand-written pass and leaves the two plain GEMMs (``dX = dZ W``, ``dW = dZ^T X``) to
+hipBLASLt through ``torch.matmul`` (library GEMMs for plain products, by design).
+CPU / fp32 inputs use ``F.linear`` -- also the oracle of the kernel tests.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+
+ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2}
+_declared = False
+_ws = {}
+
+
+def _lib():
+    global _declared
+    lib = hip.lib()
+    if not _declared:
+        P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        hip.declare("dtf_gemm_bias_act", [P, P, P, I, P, P, P, I, I, I, I, P])
+        hip.declare("dtf_act_bwd_partial_floats", [L, I], L)
+        hip.declare("dtf_act_bwd_bias", [P, P, P, P, I, P, L, I, I, P])
+        _declared = True
+    return lib
+
+
+def _partial(dev, n):
+    w = _ws.get(dev)
+    if w is None or w.numel() < n:
+        w = torch.empty(max(n, 1 << 18), dtype=torch.float32, device=dev)
+        _ws[dev] = w
+    return w
+
+
+def linear_act_reference(x, weight, bias=None, act="none", residual=None):
+    y = F.linear(x, weight, bias)
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "gelu":
+        y = F.gelu(y)
+    if residual is not None:
+        y = y + residual
+    return y
+
+
+def kernel_eligible(x, weight):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0
+            and weight.is_contiguous())
+
+
+def gemm_bias_act(x2, weight, bias, act, residual=None, save_preact=False):
+    """Raw forward kernel call on 2-D operands -> (y, preact or None)."""
+    M, K = x2.shape
+    N = weight.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    pre = torch.empty_like(y) if save_preact else None
+    rc = _lib().dtf_gemm_bias_act(hip.ptr(x2), hip.ptr(weight), hip.ptr(bias), hip.dt(bias) if bias is not None else 0,
+                                  hip.ptr(residual), hip.ptr(y), hip.ptr(pre), M, N, K, ACT[act], hip.stream())
+    hip.check(rc, "dtf_gemm_bias_act")
+    return y, pre
+
+
+class _FusedLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, act):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        r2 = None
+        if residual is not None:
+            r2 = residual.reshape(-1, weight.shape[0]).contiguous()
+        y, pre = gemm_bias_act(x2, weight, bias, act, r2, save_preact=(act == "gelu"))
+        z = y if act == "relu" else pre      # relu: mask = y > 0 (fused_linear keeps relu+residual unfused)
+        ctx.save_for_backward(x2, weight, z)
+        ctx.act, ctx.has_bias, ctx.has_res, ctx.shape = act, bias is not None, residual is not None, shp
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        return y.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, z = ctx.saved_tensors
+        N = weight.shape[0]
+        dy2 = dy.reshape(-1, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        M = dy2.shape[0]
+        lib = _lib()
+        dres = dy if ctx.has_res else None
+        dbias = torch.empty(N, dtype=ctx.bias_dtype, device=dy.device) if ctx.has_bias else None
+        if ctx.act in ("relu", "gelu") or ctx.has_bias:
+            if N % 8 == 0:
+                need_dz = ctx.act in ("relu", "gelu")
+                dz = torch.empty_like(dy2) if need_dz else None
+                part = _partial(dy.device, int(lib.dtf_act_bwd_partial_floats(M, N)))
+                rc = lib.dtf_act_bwd_bias(hip.ptr(dy2), hip.ptr(z), hip.ptr(dz), hip.ptr(dbias),
+                                          hip.dt(dbias) if dbias is not None else 0, hip.ptr(part), M, N,
+                                          ACT[ctx.act], hip.stream())
+                hip.check(rc, "dtf_act_bwd_bias")
+                if dz is None:
+                    dz = dy2
+            else:
+                if ctx.act == "relu":
+                    dz = dy2 * (z > 0)
+                elif ctx.act == "gelu":
+                    zf = z.float()
+                    dz = (dy2.float() * (0.5 * (1 + torch.erf(zf * 0.7071067811865476))
+                                         + zf * torch.exp(-0.5 * zf * zf) * 0.3989422804014327)).to(dy2.dtype)
+                else:
+                    dz = dy2
+                if dbias is not None:
+                    dbias = dz.float().sum(0).to(ctx.bias_dtype)
+        else:
+            dz = dy2
+        dx = torch.matmul(dz, weight).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        dw = torch.matmul(dz.t(), x2) if ctx.needs_input_grad[1] else None
+        return dx, dw, dbias, dres, None
+
+
+def fused_linear(x, weight, bias=None, act="none", residual=None):
+    """``act(x @ weight.T + bias) (+ residual)``; the HIP path for bf16 CUDA tensors."""
+    if not kernel_eligible(x, weight) or (act == "relu" and residual is not None):
+        return linear_act_reference(x, weight, bias, act, residual)
+    return _FusedLinear.apply(x, weight, bias, residual, act)
+
+
+class FusedLinear(nn.Linear):
+    """``nn.Linear`` with the activation (and an optional residual) fused into the GEMM."""
+
+    def __init__(self, in_features, out_features, bias=True, act="none"):
+        super().__init__(in_features, out_features, bias)
+        self.act = act
+
+    def forward(self, x, residual=None):
+        return fused_linear(x, self.weight, self.bias, self.act, residual)
+
+    def extra_repr(self):
+        return super().extra_repr() + ", act=%s" % self.act

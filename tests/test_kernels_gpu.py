@@ -296,3 +296,61 @@ def test_wide_deep_trains_on_gpu(dev):
         ps.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.6 * losses[0], losses[::8]
+
+
+# ---------------------------------------------------------------------------
+# K6 MFMA GEMM + fused epilogue
+# ---------------------------------------------------------------------------
+from distributed_tensorflow_amd.ops import linear as lin  # noqa: E402
+
+
+def test_gemm_identity_with_asymmetric_b(dev):
+    """A = I, asymmetric B: catches a transposed C-write or swapped operand maps."""
+    M = N = K = 256
+    x = torch.eye(M, K, device=dev, dtype=torch.bfloat16)
+    w = (torch.arange(N, device=dev).unsqueeze(1) * 2 + torch.arange(K, device=dev).unsqueeze(0) % 7).to(torch.bfloat16)
+    y, _ = lin.gemm_bias_act(x, w, None, "none")
+    assert torch.equal(y, w.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 100, 784), (1000, 3072, 768), (8192, 768, 3072),
+                                   (77, 10, 104), (4096, 1024, 1672), (130, 264, 8)])
+@pytest.mark.parametrize("act", ["none", "relu", "gelu"])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_gemm_bias_act_forward(dev, M, N, K, act, with_res):
+    if act == "relu" and with_res:
+        pytest.skip("relu+residual stays unfused")
+    torch.manual_seed(0)
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=dev).to(torch.bfloat16)
+    r = torch.randn(M, N, device=dev).to(torch.bfloat16) if with_res else None
+    if N % 8 != 0 and with_res:
+        pytest.skip("residual needs N % 8 == 0 alignment per row")
+    y, pre = lin.gemm_bias_act(x, w, b, act, r, save_preact=(act == "gelu"))
+    ref = lin.linear_act_reference(x.float(), w.float(), b.float(), act, None if r is None else r.float())
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+    if pre is not None:
+        torch.testing.assert_close(pre.float(), torch.nn.functional.linear(x.float(), w.float(), b.float()), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "gelu"])
+def test_fused_linear_backward(dev, act):
+    torch.manual_seed(1)
+    M, K, N = 512, 256, 384
+    x = torch.randn(4, M // 4, K, device=dev).to(torch.bfloat16)
+    layer = lin.FusedLinear(K, N, act=act).to(dev).to(torch.bfloat16)
+    x1 = x.clone().requires_grad_()
+    y1 = layer(x1)
+    dy = torch.randn_like(y1)
+    y1.backward(dy)
+    x2 = x.float().requires_grad_()
+    w2, b2 = layer.weight.detach().float().requires_grad_(), layer.bias.detach().float().requires_grad_()
+    y2 = lin.linear_act_reference(x2, w2, b2, act)
+    if act == "relu":   # same mask as the kernel (knife-edge elements)
+        y2 = torch.nn.functional.linear(x2, w2, b2) * (y1.detach() > 0).float()
+    y2.backward(dy.float())
+    torch.testing.assert_close(y1.float(), y2, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(x1.grad.float(), x2.grad, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(layer.weight.grad.float(), w2.grad, rtol=3e-2, atol=0.15)
+    torch.testing.assert_close(layer.bias.grad.float(), b2.grad, rtol=3e-2, atol=0.2)
