@@ -50,6 +50,9 @@ def main():
     a = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from distributed_tensorflow_amd.utils import miopen as miopen_cache
+
+    miopen_db = miopen_cache.setup()      # shipped find-db + kernel cache (offline-tuned convs)
     import torch
     import torch.distributed as dist
 
@@ -145,7 +148,7 @@ def main():
                        "per_gpu_batch": a.batch, "image_size": a.image_size or ("299" if "inception" in key else 224),
                        "parallelism": "dp%d+ps-shard%d" % (n, n), "push": a.push, "pull": "all_gather",
                        "update_mode": a.update_mode, "optimizer": opt.kind, "bucket_mb": a.bucket_mb,
-                       "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find),
+                       "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db),
                        "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),
                        "final_loss": round(last_loss, 4)},
         }

@@ -131,6 +131,9 @@ def main(argv=None):
                        "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
 
     put = _metrics_sink(uid)
+    from ..utils import miopen as miopen_cache
+
+    miopen_cache.setup()
     from ..train.trainer import run_task
 
     rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,

@@ -1,0 +1,43 @@
+"""Ship-with-the-tree MIOpen tuning results.
+
+PyTorch-ROCm runs the convolutions of the conv nets through MIOpen.  On a fresh box MIOpen
+(a) compiles every kernel it picks (~60 s for ResNet-50's first steps) and (b) picks solvers
+from heuristics unless an exhaustive ``find`` has been run (~200 s for ResNet-50, +12.6 %
+images/s on MI355X).  Both are paid once, offline (``scripts/gpu_miopen_tune.sh``); the
+resulting user find-db / perf-db (text) and kernel cache (``*.ukdb``) live in
+``distributed_tensorflow_amd/miopen_db`` and :func:`setup` points MIOpen at a private
+writable copy of them.  This is what keeps job submit -> first step short (SURVEY 7.2
+item 2: never JIT or tune at submit time) without giving up the tuned kernels.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import tempfile
+
+_SRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "miopen_db"))
+
+
+def setup(force=False):
+    """Call before the first convolution (ideally before ``import torch``).  Idempotent.
+    Respects MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR if the user set them."""
+    if not force and ("MIOPEN_USER_DB_PATH" in os.environ or "MIOPEN_CUSTOM_CACHE_DIR" in os.environ):
+        return os.environ.get("MIOPEN_USER_DB_PATH")
+    if not os.path.isdir(_SRC) or not os.listdir(_SRC):
+        return None
+    base = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "dtf_miopen_%d" % os.getuid())
+    db, cache = os.path.join(base, "db"), os.path.join(base, "cache")
+    try:
+        os.makedirs(db, exist_ok=True)
+        os.makedirs(cache, exist_ok=True)
+        for f in os.listdir(_SRC):
+            dst = os.path.join(cache if f.endswith(".ukdb") else db, f)
+            if not os.path.exists(dst):
+                tmp = dst + ".tmp.%d" % os.getpid()
+                shutil.copyfile(os.path.join(_SRC, f), tmp)
+                os.replace(tmp, dst)
+    except OSError:
+        return None
+    os.environ["MIOPEN_USER_DB_PATH"] = db
+    os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = cache
+    return db
