@@ -37,7 +37,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="resnet50")
-    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0: 256 for resnet, model default otherwise)")
+    ap.add_argument("--model-arg", action="append", default=[], help="key=value forwarded to the model's build()")
     ap.add_argument("--image-size", type=int, default=0, help="0: model default (224 / 299)")
     ap.add_argument("--update-mode", default="sync", choices=["sync", "stale"])
     ap.add_argument("--push", default="reduce_scatter", choices=["reduce_scatter", "all_to_all"])
@@ -75,15 +76,25 @@ def main():
 
     key = a.model.lower().replace("-", "_")
     mod = get_model_module(key)
-    kw = {}
+    kw = dict(kv.split("=", 1) for kv in a.model_arg)
     if key.startswith("resnet") and key != "resnet50":
         kw["depth"] = int(key[6:])
+    if getattr(mod, "NEEDS_COMM", False):
+        kw.update(comm=comm, device=dev)
+    if not a.batch:
+        a.batch = {"inception_v3": 128, "inception3": 128, "bert": 16, "bert_base": 16, "wide_deep": 16384,
+                   "mnist_mlp": 256, "mnist": 256}.get(key, 256)
+    unit = {"bert": "sequences/sec", "bert_base": "sequences/sec", "wide_deep": "examples/sec"}.get(key, "images/sec")
     model = mod.prepare(mod.build(**kw), dev)
     model.train()
     opt = mod.default_optimizer()
     ps = ShardedPS(list(model.named_parameters()), comm, opt, bucket_mb=a.bucket_mb,
                    update_mode=a.update_mode, push=a.push)
     bkw = {"image_size": a.image_size} if a.image_size else {}
+    if getattr(mod, "NEEDS_COMM", False):
+        bkw["model"] = model
+    if "seq_len" in kw:
+        bkw["seq_len"] = int(kw["seq_len"])
     batch = mod.synthetic_batch(a.batch, device=dev, seed=100 + comm.rank, **bkw)
 
     def step():
@@ -139,11 +150,11 @@ def main():
     base = BASELINES.get(key, {}).get(n)
     if comm.rank == 0:
         out = {
-            "metric": "images/sec (whole node) %s synthetic, PS-sharded variables" % a.model,
-            "value": round(value, 2), "unit": "images/sec", "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
+            "metric": "%s (whole node) %s synthetic, PS-sharded variables" % (unit, a.model),
+            "value": round(value, 2), "unit": unit, "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None if base is None else round(value / base, 3), "dtype": "bf16",
-            "data": "synthetic images+labels, random-init weights",
+            "data": "synthetic inputs+labels, random-init weights",
             "config": {"model": a.model + ("_v1.5" if key == "resnet50" else ""), "global_batch": global_batch,
                        "per_gpu_batch": a.batch, "image_size": a.image_size or ("299" if "inception" in key else 224),
                        "parallelism": "dp%d+ps-shard%d" % (n, n), "push": a.push, "pull": "all_gather",

@@ -1,0 +1,157 @@
+"""BERT-base pre-training (config #4: PS-sharded Adam, bf16, sequence length 512).
+
+L=12, H=768, A=12, intermediate 3072, vocab 30522, masked-LM + next-sentence heads; ~110 M
+parameters whose Adam state (fp32 master + m + v) is sharded over the PS ranks and updated
+by the K2 fused Adam shard-apply kernel.  Linear layers are :class:`FusedLinear` (K6 MFMA
+GEMM with the bias / GELU / residual epilogue fused); attention uses PyTorch SDPA (not a
+north-star kernel).
+
+Variables are named like google-research/bert checkpoints: ``bert/embeddings/word_embeddings``,
+``bert/encoder/layer_0/attention/self/query/kernel``, ``cls/predictions/transform/dense/kernel``
+(TF stores kernels ``[in, out]``; the flat shard bytes here are torch's ``[out, in]``, recorded
+as such in the checkpoint index).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops.linear import FusedLinear
+
+
+class Layer(nn.Module):
+    def __init__(self, H, A, I, p):
+        super().__init__()
+        self.A = A
+        self.qkv = FusedLinear(H, 3 * H)
+        self.attn_out = FusedLinear(H, H)
+        self.attn_ln = nn.LayerNorm(H, eps=1e-12)
+        self.inter = FusedLinear(H, I, act="gelu")
+        self.out = FusedLinear(I, H)
+        self.out_ln = nn.LayerNorm(H, eps=1e-12)
+        self.p = p
+
+    def forward(self, x, mask):
+        B, S, H = x.shape
+        qkv = self.qkv(x).view(B, S, 3, self.A, H // self.A).permute(2, 0, 3, 1, 4)
+        ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask,
+                                             dropout_p=self.p if self.training else 0.0)
+        ctx = ctx.transpose(1, 2).reshape(B, S, H)
+        x = self.attn_ln(self.attn_out(ctx, residual=x))          # residual fused in the GEMM epilogue
+        return self.out_ln(self.out(self.inter(x), residual=x))
+
+
+class Bert(nn.Module):
+    def __init__(self, vocab=30522, hidden=768, layers=12, heads=12, intermediate=3072, max_pos=512,
+                 type_vocab=2, dropout=0.0):
+        super().__init__()
+        self.hidden, self.vocab = hidden, vocab
+        self.word_embeddings = nn.Embedding(vocab, hidden)
+        self.position_embeddings = nn.Embedding(max_pos, hidden)
+        self.token_type_embeddings = nn.Embedding(type_vocab, hidden)
+        self.emb_ln = nn.LayerNorm(hidden, eps=1e-12)
+        self.layers = nn.ModuleList(Layer(hidden, heads, intermediate, dropout) for _ in range(layers))
+        self.pooler = FusedLinear(hidden, hidden)
+        self.mlm_transform = FusedLinear(hidden, hidden, act="gelu")
+        self.mlm_ln = nn.LayerNorm(hidden, eps=1e-12)
+        self.mlm_bias = nn.Parameter(torch.zeros(vocab))
+        self.nsp = nn.Linear(hidden, 2)
+        self.apply(self._init)
+
+    @staticmethod
+    def _init(m):
+        if isinstance(m, (nn.Linear, nn.Embedding)):
+            nn.init.trunc_normal_(m.weight, std=0.02, a=-0.04, b=0.04)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                nn.init.zeros_(m.bias)
+
+    def forward(self, input_ids, token_type_ids, attention_mask, masked_positions):
+        B, S = input_ids.shape
+        pos = torch.arange(S, device=input_ids.device)
+        x = self.word_embeddings(input_ids) + self.position_embeddings(pos).unsqueeze(0) \
+            + self.token_type_embeddings(token_type_ids)
+        x = self.emb_ln(x)
+        mask = None
+        if attention_mask is not None:
+            mask = attention_mask[:, None, None, :].to(torch.bool)
+        for layer in self.layers:
+            x = layer(x, mask)
+        pooled = torch.tanh(self.pooler(x[:, 0]))
+        # masked-LM head on the masked positions only (max_predictions_per_seq)
+        idx = masked_positions.unsqueeze(-1).expand(-1, -1, self.hidden)
+        h = torch.gather(x, 1, idx).reshape(-1, self.hidden)
+        h = self.mlm_ln(self.mlm_transform(h))
+        mlm_logits = F.linear(h, self.word_embeddings.weight, self.mlm_bias)      # tied decoder
+        return mlm_logits, self.nsp(pooled)
+
+
+def build(layers=12, hidden=768, heads=12, intermediate=3072, vocab=30522, seq_len=512, **_):
+    return Bert(int(vocab), int(hidden), int(layers), int(heads), int(intermediate), max(512, int(seq_len)))
+
+
+def prepare(model, device):
+    device = torch.device(device)
+    if device.type == "cuda":
+        return model.to(device=device, dtype=torch.bfloat16)
+    return model.to(device)
+
+
+def tf_variable_names(model):
+    out = {}
+    ln = {"weight": "gamma", "bias": "beta"}
+    kb = {"weight": "kernel", "bias": "bias"}
+    for n, _ in model.named_parameters():
+        p = n.split(".")
+        if p[0] in ("word_embeddings", "position_embeddings", "token_type_embeddings"):
+            tf = "bert/embeddings/" + p[0]
+        elif p[0] == "emb_ln":
+            tf = "bert/embeddings/LayerNorm/" + ln[p[1]]
+        elif p[0] == "layers":
+            base = "bert/encoder/layer_%s/" % p[1]
+            sub = {"qkv": "attention/self/qkv/", "attn_out": "attention/output/dense/",
+                   "attn_ln": "attention/output/LayerNorm/", "inter": "intermediate/dense/",
+                   "out": "output/dense/", "out_ln": "output/LayerNorm/"}[p[2]]
+            tf = base + sub + (ln[p[3]] if p[2].endswith("ln") else kb[p[3]])
+        elif p[0] == "pooler":
+            tf = "bert/pooler/dense/" + kb[p[1]]
+        elif p[0] == "mlm_transform":
+            tf = "cls/predictions/transform/dense/" + kb[p[1]]
+        elif p[0] == "mlm_ln":
+            tf = "cls/predictions/transform/LayerNorm/" + ln[p[1]]
+        elif p[0] == "mlm_bias":
+            tf = "cls/predictions/output_bias"
+        elif p[0] == "nsp":
+            tf = "cls/seq_relationship/" + ("output_weights" if p[1] == "weight" else "output_bias")
+        else:
+            tf = n
+        out[n] = tf
+    return out
+
+
+def synthetic_batch(batch, device="cpu", seed=None, seq_len=512, vocab=30522, max_predictions=76, **_):
+    g = torch.Generator().manual_seed(seed) if seed is not None else None
+    seq_len = int(seq_len)
+    ids = torch.randint(1000, vocab, (batch, seq_len), generator=g)
+    types = (torch.arange(seq_len).unsqueeze(0) >= seq_len // 2).long().expand(batch, -1).contiguous()
+    mask = torch.ones(batch, seq_len, dtype=torch.long)
+    npred = min(max_predictions, max(1, int(seq_len * 0.15)))
+    pos = torch.stack([torch.randperm(seq_len, generator=g)[:npred] for _ in range(batch)])
+    labels = torch.gather(ids, 1, pos)
+    ids = ids.scatter(1, pos, 103)          # [MASK]
+    nsp = torch.randint(0, 2, (batch,), generator=g)
+    return tuple(t.to(device) for t in (ids, types, mask, pos, labels, nsp))
+
+
+def loss_fn(model, batch):
+    ids, types, mask, pos, labels, nsp = batch
+    mlm_logits, nsp_logits = model(ids, types, None if bool((mask == 1).all()) else mask, pos)
+    return F.cross_entropy(mlm_logits.float(), labels.reshape(-1)) + F.cross_entropy(nsp_logits.float(), nsp)
+
+
+def default_optimizer():
+    from ..parallel.ps_runtime import OptimizerSpec
+
+    # BERT's AdamWeightDecayOptimizer: decoupled decay 0.01, no bias correction
+    return OptimizerSpec(kind="adam", lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.01, adamw=True,
+                         bias_correction=False, max_grad_norm=1.0)

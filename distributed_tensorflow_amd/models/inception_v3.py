@@ -1,0 +1,216 @@
+"""Inception-v3 for synthetic ImageNet at 299x299 (config #5: sync-vs-async PS update
+with job cleanup; the ``tf_cnn_benchmarks --model=inception3`` row of BASELINE.md).
+
+Same MI355X recipe as ResNet: NHWC bf16, MIOpen convolutions, and every
+``conv -> BatchNorm -> ReLU`` unit (TF-slim's ``conv2d`` with ``batch_norm``) uses the K7
+fused BN+ReLU kernels.  ~23.8 M parameters without the auxiliary head (``aux_logits=True``
+adds the ~3.4 M-parameter side classifier used by the TF-slim training recipe).
+Variable names follow TF-slim's ``InceptionV3`` scope (``InceptionV3/Conv2d_1a_3x3/weights``,
+``InceptionV3/Mixed_5b/Branch_1/Conv2d_0a_1x1/BatchNorm/beta``, ``InceptionV3/Logits/...``).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..ops.batchnorm import FusedBatchNormAct
+
+
+class ConvBN(nn.Module):
+    """slim.conv2d: conv (no bias) + BatchNorm(eps=1e-3) + ReLU."""
+
+    def __init__(self, i, o, k, stride=1, padding=0):
+        super().__init__()
+        self.conv = nn.Conv2d(i, o, k, stride=stride, padding=padding, bias=False)
+        self.bn = FusedBatchNormAct(o, relu=True, eps=1e-3)
+
+    def forward(self, x):
+        return self.bn(self.conv(x))
+
+
+def _cat(xs):
+    # NHWC concat along channels keeps channels_last
+    return torch.cat(xs, 1)
+
+
+class InceptionA(nn.Module):          # Mixed_5b/5c/5d
+    def __init__(self, i, pool):
+        super().__init__()
+        self.b0 = ConvBN(i, 64, 1)
+        self.b1 = nn.Sequential(ConvBN(i, 48, 1), ConvBN(48, 64, 5, padding=2))
+        self.b2 = nn.Sequential(ConvBN(i, 64, 1), ConvBN(64, 96, 3, padding=1), ConvBN(96, 96, 3, padding=1))
+        self.b3 = ConvBN(i, pool, 1)
+
+    def forward(self, x):
+        return _cat([self.b0(x), self.b1(x), self.b2(x), self.b3(F.avg_pool2d(x, 3, 1, 1))])
+
+
+class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
+    def __init__(self, i):
+        super().__init__()
+        self.b0 = ConvBN(i, 384, 3, stride=2)
+        self.b1 = nn.Sequential(ConvBN(i, 64, 1), ConvBN(64, 96, 3, padding=1), ConvBN(96, 96, 3, stride=2))
+
+    def forward(self, x):
+        return _cat([self.b0(x), self.b1(x), F.max_pool2d(x, 3, 2)])
+
+
+class InceptionC(nn.Module):          # Mixed_6b..6e
+    def __init__(self, i, c7):
+        super().__init__()
+        self.b0 = ConvBN(i, 192, 1)
+        self.b1 = nn.Sequential(ConvBN(i, c7, 1), ConvBN(c7, c7, (1, 7), padding=(0, 3)),
+                                ConvBN(c7, 192, (7, 1), padding=(3, 0)))
+        self.b2 = nn.Sequential(ConvBN(i, c7, 1), ConvBN(c7, c7, (7, 1), padding=(3, 0)),
+                                ConvBN(c7, c7, (1, 7), padding=(0, 3)), ConvBN(c7, c7, (7, 1), padding=(3, 0)),
+                                ConvBN(c7, 192, (1, 7), padding=(0, 3)))
+        self.b3 = ConvBN(i, 192, 1)
+
+    def forward(self, x):
+        return _cat([self.b0(x), self.b1(x), self.b2(x), self.b3(F.avg_pool2d(x, 3, 1, 1))])
+
+
+class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
+    def __init__(self, i):
+        super().__init__()
+        self.b0 = nn.Sequential(ConvBN(i, 192, 1), ConvBN(192, 320, 3, stride=2))
+        self.b1 = nn.Sequential(ConvBN(i, 192, 1), ConvBN(192, 192, (1, 7), padding=(0, 3)),
+                                ConvBN(192, 192, (7, 1), padding=(3, 0)), ConvBN(192, 192, 3, stride=2))
+
+    def forward(self, x):
+        return _cat([self.b0(x), self.b1(x), F.max_pool2d(x, 3, 2)])
+
+
+class InceptionE(nn.Module):          # Mixed_7b/7c
+    def __init__(self, i):
+        super().__init__()
+        self.b0 = ConvBN(i, 320, 1)
+        self.b1 = ConvBN(i, 384, 1)
+        self.b1a = ConvBN(384, 384, (1, 3), padding=(0, 1))
+        self.b1b = ConvBN(384, 384, (3, 1), padding=(1, 0))
+        self.b2 = nn.Sequential(ConvBN(i, 448, 1), ConvBN(448, 384, 3, padding=1))
+        self.b2a = ConvBN(384, 384, (1, 3), padding=(0, 1))
+        self.b2b = ConvBN(384, 384, (3, 1), padding=(1, 0))
+        self.b3 = ConvBN(i, 192, 1)
+
+    def forward(self, x):
+        y1 = self.b1(x)
+        y2 = self.b2(x)
+        return _cat([self.b0(x), self.b1a(y1), self.b1b(y1), self.b2a(y2), self.b2b(y2),
+                     self.b3(F.avg_pool2d(x, 3, 1, 1))])
+
+
+class AuxHead(nn.Module):
+    def __init__(self, i, num_classes):
+        super().__init__()
+        self.conv0 = ConvBN(i, 128, 1)
+        self.conv1 = ConvBN(128, 768, 5)
+        self.fc = nn.Linear(768, num_classes)
+
+    def forward(self, x):
+        x = F.avg_pool2d(x, 5, 3)
+        x = self.conv1(self.conv0(x))
+        return self.fc(x.mean((2, 3)))
+
+
+class InceptionV3(nn.Module):
+    def __init__(self, num_classes=1000, aux_logits=False):
+        super().__init__()
+        self.Conv2d_1a_3x3 = ConvBN(3, 32, 3, stride=2)
+        self.Conv2d_2a_3x3 = ConvBN(32, 32, 3)
+        self.Conv2d_2b_3x3 = ConvBN(32, 64, 3, padding=1)
+        self.Conv2d_3b_1x1 = ConvBN(64, 80, 1)
+        self.Conv2d_4a_3x3 = ConvBN(80, 192, 3)
+        self.Mixed_5b = InceptionA(192, 32)
+        self.Mixed_5c = InceptionA(256, 64)
+        self.Mixed_5d = InceptionA(288, 64)
+        self.Mixed_6a = InceptionB(288)
+        self.Mixed_6b = InceptionC(768, 128)
+        self.Mixed_6c = InceptionC(768, 160)
+        self.Mixed_6d = InceptionC(768, 160)
+        self.Mixed_6e = InceptionC(768, 192)
+        self.AuxLogits = AuxHead(768, num_classes) if aux_logits else None
+        self.Mixed_7a = InceptionD(768)
+        self.Mixed_7b = InceptionE(1280)
+        self.Mixed_7c = InceptionE(2048)
+        self.Logits = nn.Linear(2048, num_classes)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
+                nn.init.trunc_normal_(m.weight, std=0.1, a=-0.2, b=0.2)
+
+    def forward(self, x):
+        x = self.Conv2d_2b_3x3(self.Conv2d_2a_3x3(self.Conv2d_1a_3x3(x)))
+        x = F.max_pool2d(x, 3, 2)
+        x = self.Conv2d_4a_3x3(self.Conv2d_3b_1x1(x))
+        x = F.max_pool2d(x, 3, 2)
+        x = self.Mixed_5d(self.Mixed_5c(self.Mixed_5b(x)))
+        x = self.Mixed_6e(self.Mixed_6d(self.Mixed_6c(self.Mixed_6b(self.Mixed_6a(x)))))
+        aux = self.AuxLogits(x) if (self.AuxLogits is not None and self.training) else None
+        x = self.Mixed_7c(self.Mixed_7b(self.Mixed_7a(x)))
+        logits = self.Logits(x.mean((2, 3)))
+        return (logits, aux) if aux is not None else logits
+
+
+def build(num_classes=1000, aux_logits=False, **_):
+    if isinstance(aux_logits, str):
+        aux_logits = aux_logits.lower() in ("1", "true", "yes")
+    return InceptionV3(int(num_classes), bool(aux_logits))
+
+
+def prepare(model, device):
+    device = torch.device(device)
+    if device.type == "cuda":
+        return model.to(device=device, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    return model.to(device)
+
+
+def tf_variable_names(model):
+    bn = {"weight": "gamma", "bias": "beta", "running_mean": "moving_mean", "running_var": "moving_variance"}
+    out = {}
+    names = [n for n, _ in model.named_parameters()] + [n for n, _ in model.named_buffers()]
+    for n in names:
+        parts = n.split(".")
+        leaf = parts[-1]
+        if parts[0] == "Logits":
+            tf = "Logits/Conv2d_1c_1x1/" + ("weights" if leaf == "weight" else "biases")
+        elif parts[0] == "AuxLogits" and parts[1] == "fc":
+            tf = "AuxLogits/Conv2d_2b_1x1/" + ("weights" if leaf == "weight" else "biases")
+        else:
+            scope = "/".join(p for p in parts[:-2])
+            # branch modules b0..b3 -> Branch_0..3 ; sequential indices -> Conv2d_0<letter>
+            toks = []
+            for p in parts[:-2]:
+                if p[0] == "b" and p[1:2].isdigit():
+                    toks.append("Branch_%s%s" % (p[1], ("_" + p[2:]) if len(p) > 2 else ""))
+                elif p.isdigit():
+                    toks.append("Conv2d_0%s" % "abcdefgh"[int(p)])
+                else:
+                    toks.append(p)
+            scope = "/".join(toks)
+            tf = scope + ("/weights" if parts[-2] == "conv" else "/BatchNorm/" + bn[leaf])
+        out[n] = "InceptionV3/" + tf
+    return out
+
+
+def synthetic_batch(batch, device="cpu", dtype=None, seed=None, image_size=299, num_classes=1000, **_):
+    device = torch.device(device)
+    g = torch.Generator().manual_seed(seed) if seed is not None else None
+    dtype = dtype or (torch.bfloat16 if device.type == "cuda" else torch.float32)
+    x = torch.randn(batch, 3, image_size, image_size, generator=g).to(device=device, dtype=dtype)
+    x = x.contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, num_classes, (batch,), generator=g).to(device)
+    return x, y
+
+
+def loss_fn(model, batch):
+    x, y = batch
+    out = model(x)
+    if isinstance(out, tuple):
+        return F.cross_entropy(out[0].float(), y) + 0.4 * F.cross_entropy(out[1].float(), y)
+    return F.cross_entropy(out.float(), y)
+
+
+def default_optimizer():
+    from ..parallel.ps_runtime import OptimizerSpec
+
+    # tf_cnn_benchmarks trains every model with momentum SGD by default
+    return OptimizerSpec(kind="momentum", lr=0.045, momentum=0.9, weight_decay=4e-5)
