@@ -72,10 +72,7 @@ class AttrDict(dict):
 # HBM accounting without touching HIP in the service process
 # ---------------------------------------------------------------------------
 
-def hbm_used_bytes():
-    """Per-device used VRAM from sysfs (``mem_info_vram_used``), index order =
-    DRM card order.  Empty list when no amdgpu device is visible (CPU box)."""
-    out = []
+def _hbm_sysfs():
     cards = []
     for p in glob.glob("/sys/class/drm/card[0-9]*/device/mem_info_vram_used"):
         try:
@@ -83,6 +80,7 @@ def hbm_used_bytes():
         except ValueError:
             continue
         cards.append((idx, p))
+    out = []
     for _, p in sorted(cards):
         try:
             with open(p) as f:
@@ -92,9 +90,83 @@ def hbm_used_bytes():
     return out
 
 
+def _hbm_rocm_smi():
+    import shutil
+
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return []
+    try:
+        r = subprocess.run([exe, "--showmeminfo", "vram", "--json"], capture_output=True, text=True, timeout=20)
+        txt = r.stdout[r.stdout.index("{"):]
+        doc = json.loads(txt)
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return []
+    cards = []
+    for k, v in doc.items():
+        if k.startswith("card"):
+            try:
+                cards.append((int(k[4:]), int(v.get("VRAM Total Used Memory (B)", -1))))
+            except (TypeError, ValueError):
+                pass
+    return [u for _, u in sorted(cards)]
+
+
+_hbm_source = None
+
+
+def hbm_used_bytes():
+    """Per-device used VRAM in bytes without touching HIP in the service process: sysfs
+    (``mem_info_vram_used``) when the container exposes it, else ``rocm-smi --json``.
+    Empty list when no amdgpu device is visible (CPU box)."""
+    global _hbm_source
+    if _hbm_source in (None, "sysfs"):
+        out = _hbm_sysfs()
+        if out:
+            _hbm_source = "sysfs"
+            return out
+    if _hbm_source in (None, "rocm-smi"):
+        out = _hbm_rocm_smi()
+        if out:
+            _hbm_source = "rocm-smi"
+            return out
+    if _hbm_source is None:
+        _hbm_source = "none"
+    return []
+
+
+def probe_hbm(gpus, python=None, timeout=90):
+    """``[{"gpu", "free", "total", "used"}]`` measured by a fresh child process through
+    hipMemGetInfo (the service process itself never initialises HIP)."""
+    code = ("import json,torch;out=[]\n"
+            "for i in range(torch.cuda.device_count()):\n"
+            "    f,t=torch.cuda.mem_get_info(i);out.append({'free':f,'total':t,'used':t-f})\n"
+            "print('HBM'+json.dumps(out))")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=",".join(str(g) for g in gpus))
+    try:
+        r = subprocess.run([python or sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                           timeout=timeout)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("HBM")][-1]
+        out = json.loads(line[3:])
+    except (OSError, IndexError, ValueError, subprocess.SubprocessError):
+        return None
+    for g, o in zip(gpus, out):
+        o["gpu"] = g
+    return out
+
+
 def visible_gpu_count(default=0):
     n = len(hbm_used_bytes())
-    return n if n else default
+    if n:
+        return n
+    if os.path.exists("/dev/kfd"):
+        try:
+            import torch
+
+            return int(torch.cuda.device_count())      # does not initialise the GPU
+        except Exception:
+            pass
+    return default
 
 
 class _Task:
@@ -344,19 +416,32 @@ class LocalCluster:
         return how
 
     def _verify_reclaim(self, t):
-        if not t.hbm_before:
+        """After a GPU task was killed: is its HBM back?  Authoritative check = a fresh
+        process asking the driver (``hipMemGetInfo`` through ``torch.cuda.mem_get_info``) on
+        exactly the devices the task held; the sysfs / rocm-smi counters are recorded too when
+        the container exposes them (on some boxes they read 0 whatever is allocated)."""
+        if not t.gpus:
             return None
         slack = self._cfg.getint("launcher", "hbm_reclaim_slack_mb", 64) << 20
-        deadline = time.time() + 5.0
-        while True:
-            used = hbm_used_bytes()
-            after = {g: used[g] for g in t.hbm_before if g < len(used)}
-            ok = all(after[g] <= t.hbm_before[g] + slack for g in after)
-            if ok or time.time() > deadline:
-                break
-            time.sleep(0.1)
-        rep = {"task": t.name, "gpus": list(t.hbm_before), "before": t.hbm_before, "after": after,
-               "reclaimed": ok}
+        rep = {"task": t.name, "gpus": list(t.gpus)}
+        if t.hbm_before:
+            deadline = time.time() + 5.0
+            while True:
+                used = hbm_used_bytes()
+                after = {g: used[g] for g in t.hbm_before if g < len(used)}
+                ok = all(after[g] <= t.hbm_before[g] + slack for g in after)
+                if ok or time.time() > deadline:
+                    break
+                time.sleep(0.1)
+            rep.update(counter_before=t.hbm_before, counter_after=after, counter_ok=ok)
+        probe = probe_hbm(t.gpus, self._python)
+        if probe is not None:
+            # a context-less device shows only the driver's own reservation as used
+            limit = max(slack, 2 << 30)
+            rep["probe"] = probe
+            rep["reclaimed"] = all(p["used"] <= limit for p in probe)
+        else:
+            rep["reclaimed"] = rep.get("counter_ok")
         self.reclaim_reports.append(rep)
         log.info("HBM reclaim %s", rep)
         return rep
