@@ -8,10 +8,19 @@ import pytest
 from distributed_tensorflow_amd.utils.store import MemoryStore, StoreClient, StoreServer
 
 
-@pytest.fixture(params=["memory", "resp"])
+@pytest.fixture(params=["memory", "resp", "native"])
 def rc(request):
     if request.param == "memory":
         yield MemoryStore()
+    elif request.param == "native":
+        from distributed_tensorflow_amd.native.build import spawn_store
+
+        proc, port = spawn_store()
+        c = StoreClient("127.0.0.1", port)
+        yield c
+        c.close()
+        proc.kill()
+        proc.wait()
     else:
         with StoreServer("127.0.0.1", 0) as srv:
             c = StoreClient(srv.host, srv.port)
@@ -99,3 +108,37 @@ def test_hincrby_is_atomic_across_clients():
         [t.start() for t in ts]
         [t.join() for t in ts]
         assert StoreClient(srv.host, srv.port).hget("h", "n") == "800"
+
+
+def test_native_server_blpop_wakeup_and_atomic_counters():
+    """dtf-stored (C++ epoll server): BLPOP 0 wakes on RPUSH, counters stay atomic under 4 clients."""
+    from distributed_tensorflow_amd.native.build import spawn_store
+
+    proc, port = spawn_store()
+    try:
+        consumer, producer = StoreClient("127.0.0.1", port), StoreClient("127.0.0.1", port)
+        got = []
+        t = threading.Thread(target=lambda: got.append(consumer.blpop(["a", "dq"], 0)))
+        t.start()
+        time.sleep(0.2)
+        assert not got
+        producer.rpush("dq", "job1", "job2")
+        t.join(3)
+        assert got == [("dq", "job1")]
+        assert producer.lrange("dq", 0, -1) == ["job2"]
+
+        def work():
+            c = StoreClient("127.0.0.1", port)
+            for _ in range(500):
+                c.hincrby("h", "n", 1)
+        ts = [threading.Thread(target=work) for _ in range(4)]
+        [x.start() for x in ts]
+        [x.join() for x in ts]
+        assert producer.hget("h", "n") == "2000"
+        with producer.pipeline() as p:
+            p.sadd("s", "x")
+            p.set("k", "v")
+            assert len(p.execute()) == 2
+    finally:
+        proc.kill()
+        proc.wait()
