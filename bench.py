@@ -69,7 +69,8 @@ def main():
             sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     hip.lib()
-    comm = Comm.from_env()
+    # DTF_FORCE_COMM=1: keep a live 1-rank RCCL group so the collectives really run on one GPU
+    comm = Comm.from_env(force=bool(int(os.environ.get("DTF_FORCE_COMM", "0"))))
     dev = comm.device
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     torch.manual_seed(1234)

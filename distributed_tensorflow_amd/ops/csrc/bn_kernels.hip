@@ -21,6 +21,7 @@
 // 64 channels (8 lanes x 8 channels = one 128-B line per row) x 32 rows per
 // iteration, 4 iterations unrolled so every lane keeps 4-8 16-B loads in flight.
 #include "dtf_common.h"
+#include <stdlib.h>
 
 #define BN_CT 64          // channels per block tile
 #define BN_ROWS 32        // rows per block iteration
@@ -341,7 +342,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
 // ---------------------------------------------------------------------------
 static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, int* ctiles) {
     const int ct = (C + BN_CT - 1) / BN_CT;
-    int64_t want = 1024 / ct;                 // ~4 blocks per CU in total
+    static int target = 0;
+    if (target == 0) {
+        const char* e = getenv("DTF_BN_BLOCKS");
+        target = e ? atoi(e) : 1024;          // ~4 blocks per CU in total
+        if (target < 64) target = 1024;
+    }
+    int64_t want = target / ct;
     if (want < 1) want = 1;
     const int64_t quantum = BN_ROWS * BN_UNROLL;
     int64_t max_blocks = (M + quantum - 1) / quantum;

@@ -27,11 +27,15 @@ import torch.distributed as dist
 
 
 class Comm:
-    def __init__(self, rank=0, world_size=1, device=None, group=None, backend=None):
+    def __init__(self, rank=0, world_size=1, device=None, group=None, backend=None, live=None):
         self.rank, self.world_size = rank, world_size
+        # live: collectives really go to the backend.  A 1-rank communicator is normally a
+        # no-op; ``from_env(force=True)`` makes it live so that the whole RCCL call path
+        # (streams, in-place slices, bf16) can be exercised on a single GPU.
+        self.live = (world_size > 1) if live is None else bool(live)
         self.device = device or torch.device("cpu")
         self.group = group
-        self.backend = backend or ("none" if world_size == 1 else dist.get_backend(group))
+        self.backend = backend or ("none" if not self.live else dist.get_backend(group))
 
     # -- construction ---------------------------------------------------------
     @classmethod
@@ -39,7 +43,7 @@ class Comm:
         return cls(0, 1, device)
 
     @classmethod
-    def from_env(cls, device=None, backend=None, timeout_s=600):
+    def from_env(cls, device=None, backend=None, timeout_s=600, force=False):
         """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
         (set by torchrun, or by ``service/entry.py`` from the job's host lists)."""
         world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -51,8 +55,11 @@ class Comm:
                 device = torch.device("cpu")
         if device.type == "cuda":
             torch.cuda.set_device(device)
-        if world == 1:
+        if world == 1 and not force:
             return cls(0, 1, device)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         if not dist.is_initialized():
             backend = backend or ("nccl" if device.type == "cuda" else "gloo")
             kw = {}
@@ -60,48 +67,48 @@ class Comm:
                 kw["device_id"] = device
             dist.init_process_group(backend, rank=rank, world_size=world,
                                     timeout=datetime.timedelta(seconds=timeout_s), **kw)
-        return cls(dist.get_rank(), dist.get_world_size(), device, None, dist.get_backend())
+        return cls(dist.get_rank(), dist.get_world_size(), device, None, dist.get_backend(), live=True)
 
     def subgroup(self, ranks):
         """Communicator over a subset of ranks (every rank must call this)."""
         g = dist.new_group(ranks)
         if self.rank not in ranks:
             return None
-        return Comm(ranks.index(self.rank), len(ranks), self.device, g, self.backend)
+        return Comm(ranks.index(self.rank), len(ranks), self.device, g, self.backend, live=True)
 
     # -- collectives ------------------------------------------------------------
     def reduce_scatter(self, out_shard, in_full, async_op=False):
-        if self.world_size == 1:
+        if not self.live:
             if out_shard.data_ptr() != in_full.data_ptr():
                 out_shard.copy_(in_full[:out_shard.numel()])
             return None
         return dist.reduce_scatter_tensor(out_shard, in_full, group=self.group, async_op=async_op)
 
     def all_gather(self, out_full, in_shard, async_op=False):
-        if self.world_size == 1:
+        if not self.live:
             if out_full.data_ptr() != in_shard.data_ptr():
                 out_full[:in_shard.numel()].copy_(in_shard)
             return None
         return dist.all_gather_into_tensor(out_full, in_shard, group=self.group, async_op=async_op)
 
     def all_to_all(self, out, inp, out_splits=None, in_splits=None, async_op=False):
-        if self.world_size == 1:
+        if not self.live:
             out.copy_(inp)
             return None
         return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=async_op)
 
     def all_reduce(self, t, op=dist.ReduceOp.SUM, async_op=False):
-        if self.world_size == 1:
+        if not self.live:
             return None
         return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
 
     def broadcast(self, t, src=0, async_op=False):
-        if self.world_size == 1:
+        if not self.live:
             return None
         return dist.broadcast(t, src=self._global(src), group=self.group, async_op=async_op)
 
     def reduce(self, t, dst=0, async_op=False):
-        if self.world_size == 1:
+        if not self.live:
             return None
         return dist.reduce(t, dst=self._global(dst), group=self.group, async_op=async_op)
 
@@ -113,7 +120,7 @@ class Comm:
         return self._local(r)
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.live:
             if self.device.type == "cuda":
                 dist.barrier(group=self.group, device_ids=[self.device.index])
             else:
@@ -126,5 +133,5 @@ class Comm:
         return r if self.group is None else dist.get_group_rank(self.group, r)
 
     def close(self):
-        if self.world_size > 1 and self.group is None and dist.is_initialized():
+        if self.live and self.group is None and dist.is_initialized():
             dist.destroy_process_group()

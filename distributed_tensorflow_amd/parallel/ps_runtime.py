@@ -86,6 +86,7 @@ class ShardedPS:
         assert push in ("reduce_scatter", "all_to_all"), push
         self.update_mode, self.push = update_mode, push
         W, r = self.comm.world_size, self.comm.rank
+        self._dist = self.comm.live          # collectives are real (W > 1, or a forced 1-rank group)
         esize = torch.empty((), dtype=self.wire_dtype).element_size()
         self.layout = FlatLayout([(n, p.numel()) for n, p in self.named_params], W,
                                  max(1, int(bucket_mb * (1 << 20) / esize)))
@@ -98,7 +99,7 @@ class ShardedPS:
             if self.opt.kind in ("momentum", "adam") else None
         self.slot_v = torch.zeros(L.shard_total, dtype=torch.float32, device=dev) \
             if self.opt.kind == "adam" else None
-        if W > 1:
+        if self._dist:
             self.grad_shard = torch.zeros(L.total if push == "all_to_all" else L.shard_total,
                                           dtype=self.wire_dtype, device=dev)
             self.shard_out = torch.zeros(L.shard_total, dtype=self.wire_dtype, device=dev)
@@ -114,7 +115,7 @@ class ShardedPS:
         self._lr = self.opt.lr
 
         # -- bind model parameters to the flat pull buffer (zero-copy pull) ---
-        if broadcast_init and W > 1:
+        if broadcast_init and self._dist:
             for p in self.params:
                 self.comm.broadcast(p.data, 0)
         self.zero_copy = []
@@ -188,7 +189,7 @@ class ShardedPS:
     def _push(self, b):
         L, W = self.layout, self.comm.world_size
         bk = L.buckets[b]
-        if W == 1:
+        if not self._dist:
             return self.grad_flat[bk.start:bk.start + bk.size], 1, 0
         full = self.grad_flat[bk.start:bk.start + bk.size]
         if self.push == "all_to_all":
@@ -203,7 +204,7 @@ class ShardedPS:
         L, W, r = self.layout, self.comm.world_size, self.comm.rank
         bk = L.buckets[b]
         sl = slice(bk.shard_off, bk.shard_off + bk.shard)
-        if W == 1:
+        if not self._dist:
             dst = self.pull_staging if self.update_mode == "stale" else self.param_flat
             p_out = dst[bk.start:bk.start + bk.size]
         else:
@@ -229,7 +230,7 @@ class ShardedPS:
 
     def _pull(self, b):
         L, W = self.layout, self.comm.world_size
-        if W == 1:
+        if not self._dist:
             return
         bk = L.buckets[b]
         dst = self.pull_staging if self.update_mode == "stale" else self.param_flat
@@ -283,7 +284,7 @@ class ShardedPS:
                         acc += g[s * stride:s * stride + bk.shard].float()
                     g = acc.to(self.wire_dtype)
                     pushed[b] = (g, 1, 0)
-                n = bk.shard if self.comm.world_size > 1 else bk.size
+                n = bk.shard if self._dist else bk.size
                 reduce_ops.sumsq(g[:n], self.gnorm_sq, accumulate=not first)
                 first = False
             self.comm.all_reduce(self.gnorm_sq)
