@@ -53,8 +53,13 @@ def linear_act_reference(x, weight, bias=None, act="none", residual=None):
     return y
 
 
+import os as _os
+
+_DISABLED = _os.environ.get("DTF_FUSED_LINEAR", "1") == "0"      # A/B switch for benchmarking only
+
+
 def kernel_eligible(x, weight):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0
+    return (not _DISABLED and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0
             and weight.is_contiguous())
 
 
