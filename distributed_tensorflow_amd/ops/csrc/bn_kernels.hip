@@ -52,7 +52,9 @@ __device__ __forceinline__ void st8bf(unsigned short* p, const float (&v)[8]) {
 }
 
 // partial[(blockIdx.x * 2 + stat) * C + c]
-template <int MODE>
+// U = rows in flight per lane: the single-operand statistics pass needs 8 (64 B per lane is too
+// little to cover the HBM latency: 3.3 TB/s measured), the two-operand backward pass 4.
+template <int MODE, int U>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ dy,
                                                         const unsigned char* __restrict__ mask,
@@ -81,12 +83,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
     }
     const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
     if (cvalid) {
-        for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
-            float xv[BN_UNROLL][8], dv[BN_UNROLL][8];
-            unsigned mb[BN_UNROLL];
-            bool ok[BN_UNROLL];
+        for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * U) {
+            float xv[U][8], dv[U][8];
+            unsigned mb[U];
+            bool ok[U];
 #pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int64_t row = r + (int64_t)u * BN_ROWS;
                 ok[u] = row < r1;
                 if (ok[u]) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                 }
             }
 #pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) {
+            for (int u = 0; u < U; ++u) {
                 if (!ok[u]) continue;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -397,7 +399,7 @@ int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const 
     if (relu && res && !mask) return -22;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
-    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS>), dim3(nb, ct), dim3(256), 0, stream,
+    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream,
                        (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, nullptr, partial, M, C, rpb);
     const float inv_count = 1.0f / (float)M;
     const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
@@ -440,7 +442,7 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
     bn_grid(M, C, &nb, &rpb, &ct);
     const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x;
     const unsigned char* ms = (const unsigned char*)mask;
-#define RED(MODE) hipLaunchKernelGGL((bn_reduce_kernel<MODE>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, rpb)
+#define RED(MODE) hipLaunchKernelGGL((bn_reduce_kernel<MODE, BN_UNROLL>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, rpb)
     if (relu_mode == BN_BWD_RELU_X) RED(BN_BWD_RELU_X);
     else if (relu_mode == BN_BWD_RELU_MASK) RED(BN_BWD_RELU_MASK);
     else RED(BN_BWD_PLAIN);
