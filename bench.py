@@ -136,6 +136,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    t_host = time.perf_counter() - t0          # time to ENQUEUE the steps (host-side cost)
     torch.cuda.synchronize()
     comm.barrier()
     torch.cuda.synchronize()
@@ -162,6 +163,7 @@ def main():
                        "update_mode": a.update_mode, "optimizer": opt.kind, "bucket_mb": a.bucket_mb,
                        "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db),
                        "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),
+                       "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
                        "final_loss": round(last_loss, 4)},
         }
         print(json.dumps(out), flush=True)

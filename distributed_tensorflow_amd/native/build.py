@@ -24,7 +24,7 @@ def build(force=False, verbose=True):
 
 def spawn_store(port=0, host="127.0.0.1"):
     """Start ``dtf-stored``; returns ``(Popen, port)`` once it is listening."""
-    exe = build(verbose=False)
+    exe = os.environ.get("DTF_STORED_EXE") or build(verbose=False)     # e.g. the ASan/UBSan variant
     p = subprocess.Popen([exe, "--host", host, "--port", str(port)], stdout=subprocess.PIPE, text=True)
     line = p.stdout.readline()
     if "listening" not in line:

@@ -29,6 +29,7 @@ True any-order asynchronous updates exist in the dedicated placement
 from __future__ import annotations
 
 import contextlib
+import os
 from dataclasses import dataclass
 
 import torch
@@ -38,6 +39,23 @@ from ..ops import optim as optim_ops
 from ..ops import reduce as reduce_ops
 from .comm import Comm
 from .layout import FlatLayout
+
+
+_TRACE = os.environ.get("DTF_TRACE", "0") == "1"
+
+
+@contextlib.contextmanager
+def trace_range(name):
+    """roctx range (``torch.cuda.nvtx`` is roctx on ROCm) around a PS pipeline stage when
+    ``DTF_TRACE=1``: shows pack / push / apply / pull in rocprofv3 ``--marker-trace`` timelines."""
+    if _TRACE and torch.cuda.is_available():
+        torch.cuda.nvtx.range_push(name)
+        try:
+            yield
+        finally:
+            torch.cuda.nvtx.range_pop()
+    else:
+        yield
 
 
 @dataclass
@@ -241,10 +259,14 @@ class ShardedPS:
         """pack -> push -> apply -> pull of one bucket on the comm stream."""
         self._launched[b] = True
         with self._on_comm_stream():
-            self._pack(b)
-            g, nsrc, stride = self._push(b)
-            self._apply(b, g, nsrc, stride)
-            self._pull(b)
+            with trace_range("ps/pack/b%d" % b):
+                self._pack(b)
+            with trace_range("ps/push/b%d" % b):
+                g, nsrc, stride = self._push(b)
+            with trace_range("ps/apply/b%d" % b):
+                self._apply(b, g, nsrc, stride)
+            with trace_range("ps/pull/b%d" % b):
+                self._pull(b)
 
     # ------------------------------------------------------------------ step
     def step(self):

@@ -356,6 +356,11 @@ class LocalCluster:
         t.status.update(active=1, phase="Running", startTime=time.time())
         self._emit("MODIFIED", t)
         threading.Thread(target=self._reap, args=(t,), name="wait-" + t.name, daemon=True).start()
+        deadline = t.body["spec"].get("activeDeadlineSeconds")
+        if deadline and not t.name.split("-")[-3] == "ps":
+            timer = threading.Timer(float(deadline), self._deadline_exceeded, args=(t,))
+            timer.daemon = True
+            timer.start()
 
     def _reap(self, t):
         rc = t.proc.wait()
@@ -370,6 +375,15 @@ class LocalCluster:
                 t.status.update(active=0, failed=1, phase="Failed", completionTime=time.time())
             self._emit("MODIFIED", t)
             self._schedule()
+
+    def _deadline_exceeded(self, t):
+        """activeDeadlineSeconds: a task still running past its deadline is killed and reported
+        failed (reason DeadlineExceeded) -- the heartbeat-free way to catch ranks hung in a collective."""
+        if t.proc is None or t.proc.poll() is not None or t.deleted:
+            return
+        log.warning("task %s exceeded its deadline; killing", t.name)
+        t.status["message"] = "DeadlineExceeded"
+        self._kill(t)
 
     def _release_gpus(self, t):
         for g in t.gpus:

@@ -46,6 +46,9 @@ def validate_spec(info):
     gpu = res.get("gpu", 0)
     if isinstance(gpu, bool) or not isinstance(gpu, int) or gpu < 0:
         raise SpecError("resource.gpu must be a non-negative integer")
+    to = info.get("timeout", 0)
+    if isinstance(to, bool) or not isinstance(to, (int, float)) or to < 0:
+        raise SpecError("timeout must be a non-negative number of seconds")
     return counts
 
 
@@ -110,12 +113,17 @@ def gen_job(uid, work_type, seq, count, info, ps, workers, cfg=None):
     res = gen_resources(info.get("resource"), work_type, cfg)
     if res:
         container["resources"] = res
+    spec_extra = {}
+    if info.get("timeout"):
+        # job-level time limit (k8s activeDeadlineSeconds); the launcher fails the task when it expires
+        spec_extra["activeDeadlineSeconds"] = int(info["timeout"])
     return {
         "apiVersion": "batch/v1",
         "kind": "Job",
         "metadata": {"name": tf_id},
         "spec": {
             "backoffLimit": 0,
+            **spec_extra,
             "template": {
                 "metadata": {"name": tf_id, "labels": {"tf": tf_id}},
                 "spec": {"restartPolicy": "Never", "containers": [container]},

@@ -155,3 +155,15 @@ def test_rollback_on_partial_failure(aio):
     assert a.cluster.list_namespaced_job("default")["items"] == []      # nothing leaked
     assert a.cluster.dns_map() == {}
     assert a.store.smembers("running_uids") == set()
+
+
+def test_job_timeout_kills_hung_workers_and_cleans_up(aio):
+    """`timeout` in the job spec -> activeDeadlineSeconds: hung workers are failed by the launcher,
+    the failure path reaps everything."""
+    a, port = aio
+    status, names = _post(port, {"file": "sleep:600", "timeout": 1, "detail": {"ps": 1, "worker": 2}})
+    assert status == 200
+    uid = parse_task_name(names[0])[0]
+    rec = _wait(lambda: (lambda r: r if r.get("t_cleaned") else None)(json.loads(a.store.get(uid))), timeout=30)
+    assert rec and rec["status"] == "failed"
+    assert a.cluster.list_namespaced_job("default")["items"] == [] and a.cluster.dns_map(uid) == {}
