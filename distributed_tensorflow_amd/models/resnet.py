@@ -20,11 +20,14 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct
+from ..ops.conv import Conv1x1
 
 _DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
 
 def _conv(i, o, k, stride=1):
+    if k == 1 and stride == 1:
+        return Conv1x1(i, o)          # NHWC 1x1 = GEMM: per-product kernel choice (ops/conv.py)
     return nn.Conv2d(i, o, k, stride=stride, padding=k // 2, bias=False)
 
 

@@ -1,0 +1,76 @@
+"""1x1 stride-1 convolution on NHWC tensors as plain GEMMs where that is faster.
+
+In NHWC a 1x1 convolution *is* a GEMM with no data movement:
+``Y[M, Cout] = X[M, Cin] . W[Cout, Cin]^T`` with ``M = N*H*W``.  Measured on MI355X at batch 256
+(``scripts/conv1x1_bench.py``, MIOpen with the shipped tuning DB vs hipBLASLt):
+
+* forward:        MIOpen's implicit-GEMM kernels win except for Cin >= 1024;
+* data gradient   ``dX = dY . W``: the plain GEMM wins for Cin >= 128 (35 vs 62 us at 14x14, 256->1024);
+* weight gradient ``dW = dY^T . X`` (reduction over M ~ 10^5..10^6): MIOpen's split-K kernels win by
+  5-10x -- the library GEMM has no good schedule for that shape.
+
+``Conv1x1`` therefore picks per product; the convolution library and the GEMM library are both
+"plain library" calls (the hand-written kernels of this package are the fused ops around them).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_MM_BWD_DATA_MIN_CIN = 128
+_MM_FWD_MIN_CIN = 1024
+
+
+def _rows(x):
+    """NHWC-dense [N,C,H,W] -> contiguous [N*H*W, C] view (no copy)."""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        if cin >= _MM_FWD_MIN_CIN:
+            y2 = torch.matmul(_rows(x), weight.reshape(cout, cin).t())
+            N, _, H, W = x.shape
+            return y2.view(N, H, W, cout).permute(0, 3, 1, 2)
+        return F.conv2d(x, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        cout, cin = weight.shape[0], weight.shape[1]
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        need_dx, need_dw = ctx.needs_input_grad
+        if need_dx and cin >= _MM_BWD_DATA_MIN_CIN:
+            N, _, H, W = x.shape
+            dx = torch.matmul(_rows(dy), weight.reshape(cout, cin)).view(N, H, W, cin).permute(0, 3, 1, 2)
+            need_dx = False
+        if need_dx or need_dw:
+            gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
+                                                            [0, 0], 1, [need_dx, need_dw, False])
+            if need_dx:
+                dx = gx
+            dw = gw if need_dw else None
+        return dx, dw
+
+
+def conv1x1(x, weight):
+    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and weight.shape[2] == 1 and weight.shape[3] == 1):
+        return _Conv1x1Fn.apply(x, weight)
+    return F.conv2d(x, weight)
+
+
+class Conv1x1(nn.Conv2d):
+    """``nn.Conv2d(cin, cout, 1, bias=False)`` with the per-product kernel choice above."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(in_channels, out_channels, 1, bias=False)
+
+    def forward(self, x):
+        return conv1x1(x, self.weight)

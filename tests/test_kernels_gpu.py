@@ -441,3 +441,24 @@ def test_sharded_ps_through_rccl_single_rank(dev, push):
     for p, q in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(p, q)
     comm.barrier()
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 256, 28), (256, 64, 14), (1024, 256, 7), (2048, 512, 7)])
+def test_conv1x1_matches_conv2d(dev, cin, cout, hw):
+    from distributed_tensorflow_amd.ops.conv import conv1x1
+
+    torch.manual_seed(0)
+    x = torch.randn(8, cin, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(8, cout, hw, hw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x1, w1 = x.clone().requires_grad_(), w.clone().requires_grad_()
+    y1 = conv1x1(x1, w1)
+    y1.backward(dy)
+    x2, w2 = x.float().requires_grad_(), w.float().requires_grad_()
+    y2 = torch.nn.functional.conv2d(x2, w2)
+    y2.backward(dy.float())
+    assert y1.shape == y2.shape and y1.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y1.float(), y2, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(x1.grad.float(), x2.grad, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(w1.grad.float(), w2.grad, rtol=2e-2, atol=0.3)
+    assert x1.grad.is_contiguous(memory_format=torch.channels_last)
