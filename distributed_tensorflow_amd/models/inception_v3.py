@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct
+from ..ops.conv import Conv1x1
 
 
 class ConvBN(nn.Module):
@@ -20,7 +21,10 @@ class ConvBN(nn.Module):
 
     def __init__(self, i, o, k, stride=1, padding=0):
         super().__init__()
-        self.conv = nn.Conv2d(i, o, k, stride=stride, padding=padding, bias=False)
+        if k == 1 and stride == 1 and padding == 0:
+            self.conv = Conv1x1(i, o)     # NHWC 1x1 = GEMM (ops/conv.py picks the kernel per product)
+        else:
+            self.conv = nn.Conv2d(i, o, k, stride=stride, padding=padding, bias=False)
         self.bn = FusedBatchNormAct(o, relu=True, eps=1e-3)
 
     def forward(self, x):

@@ -14,12 +14,15 @@ In NHWC a 1x1 convolution *is* a GEMM with no data movement:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 _MM_BWD_DATA_MIN_CIN = 128
 _MM_FWD_MIN_CIN = 1024
+_ENABLED = os.environ.get("DTF_CONV1X1_MM", "1") != "0"      # A/B switch: 0 = everything through MIOpen
 
 
 def _rows(x):
@@ -60,7 +63,7 @@ class _Conv1x1Fn(torch.autograd.Function):
 
 
 def conv1x1(x, weight):
-    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+    if (_ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
             and weight.shape[2] == 1 and weight.shape[3] == 1):
         return _Conv1x1Fn.apply(x, weight)
     return F.conv2d(x, weight)
