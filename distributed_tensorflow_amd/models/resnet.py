@@ -50,8 +50,15 @@ class Bottleneck(nn.Module):
             self.shortcut_conv = None
 
     def forward(self, x):
+        if isinstance(self.conv1, Conv1x1):
+            # x feeds conv1 and the shortcut: the fork sums their two gradients inside conv1's dX GEMM.
+            # The shortcut's gradient comes from the K7 residual epilogue / the shortcut conv's dgrad:
+            # a fresh tensor nobody else reads, so the GEMM may accumulate into it in place.
+            y, x = self.conv1.forward_fork(x, own_skip_grad=True)
+        else:
+            y = self.conv1(x)
         sc = x if self.shortcut_conv is None else self.shortcut_bn(self.shortcut_conv(x))
-        y = self.bn1(self.conv1(x))
+        y = self.bn1(y)
         y = self.bn2(self.conv2(y))
         return self.bn3(self.conv3(y), sc)
 

@@ -462,3 +462,30 @@ def test_conv1x1_matches_conv2d(dev, cin, cout, hw):
     torch.testing.assert_close(x1.grad.float(), x2.grad, rtol=2e-2, atol=3e-2)
     torch.testing.assert_close(w1.grad.float(), w2.grad, rtol=2e-2, atol=0.3)
     assert x1.grad.is_contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("own", [False, True])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (256, 64), (1024, 256)])
+def test_conv1x1_fork_sums_shortcut_gradient(dev, cin, cout, own):
+    from distributed_tensorflow_amd.ops.conv import conv1x1_fork
+
+    torch.manual_seed(0)
+    x0 = torch.randn(8, cin, 14, 14, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(8, cout, 14, 14, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ds = torch.randn_like(x0)
+    xl, w1 = x0.clone().requires_grad_(), w.clone().requires_grad_()
+    y1, skip = conv1x1_fork(xl * 1.0, w1, own_skip_grad=own)
+    assert skip.data_ptr() != 0 and skip.shape == x0.shape
+    torch.autograd.backward([y1, skip], [dy, ds.clone()])
+    x2, w2 = x0.float().requires_grad_(), w.float().requires_grad_()
+    y2 = torch.nn.functional.conv2d(x2, w2)
+    torch.autograd.backward([y2, x2 * 1.0], [dy.float(), ds.float()])
+    torch.testing.assert_close(y1.float(), y2, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(xl.grad.float(), x2.grad, rtol=2e-2, atol=4e-2)
+    torch.testing.assert_close(w1.grad.float(), w2.grad, rtol=2e-2, atol=0.3)
+    # only one branch used: gradient of the other is absent, not an error
+    xl.grad = None
+    y1, skip = conv1x1_fork(xl * 1.0, w1)
+    y1.backward(dy)
+    torch.testing.assert_close(xl.grad.float(), x2.grad - ds.float(), rtol=2e-2, atol=4e-2)
