@@ -30,6 +30,36 @@ class ConvBN(nn.Module):
     def forward(self, x):
         return self.bn(self.conv(x))
 
+    def forward_fork(self, x):
+        """-> (self(x), x'): 1x1 heads of a mixed block hand their input on to the next branch, so the
+        branch gradients of ``x`` are summed inside the dX GEMMs instead of by separate add kernels."""
+        if isinstance(self.conv, Conv1x1):
+            y, x = self.conv.forward_fork(x, own_skip_grad=True)
+            return self.bn(y), x
+        return self.bn(self.conv(x)), x
+
+
+def _head(branch):
+    return branch[0] if isinstance(branch, nn.Sequential) else branch
+
+
+def _tail(branch, y):
+    if isinstance(branch, nn.Sequential):
+        for m in list(branch)[1:]:
+            y = m(y)
+    return y
+
+
+def _fan_out(x, branches):
+    """Run the 1x1 head of every branch on ``x`` through a chain of forks; -> (branch outputs, x for the
+    last consumer).  The last consumer (a pooling op or a strided conv) produces a fresh gradient tensor,
+    which each fork then accumulates into in place on the way back."""
+    outs = []
+    for b in branches:
+        y, x = _head(b).forward_fork(x)
+        outs.append(_tail(b, y))
+    return outs, x
+
 
 def _cat(xs):
     # NHWC concat along channels keeps channels_last
@@ -45,7 +75,8 @@ class InceptionA(nn.Module):          # Mixed_5b/5c/5d
         self.b3 = ConvBN(i, pool, 1)
 
     def forward(self, x):
-        return _cat([self.b0(x), self.b1(x), self.b2(x), self.b3(F.avg_pool2d(x, 3, 1, 1))])
+        ys, x = _fan_out(x, [self.b0, self.b1, self.b2])
+        return _cat(ys + [self.b3(F.avg_pool2d(x, 3, 1, 1))])
 
 
 class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
@@ -55,7 +86,8 @@ class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
         self.b1 = nn.Sequential(ConvBN(i, 64, 1), ConvBN(64, 96, 3, padding=1), ConvBN(96, 96, 3, stride=2))
 
     def forward(self, x):
-        return _cat([self.b0(x), self.b1(x), F.max_pool2d(x, 3, 2)])
+        (y1,), x = _fan_out(x, [self.b1])
+        return _cat([self.b0(x), y1, F.max_pool2d(x, 3, 2)])
 
 
 class InceptionC(nn.Module):          # Mixed_6b..6e
@@ -70,7 +102,8 @@ class InceptionC(nn.Module):          # Mixed_6b..6e
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
-        return _cat([self.b0(x), self.b1(x), self.b2(x), self.b3(F.avg_pool2d(x, 3, 1, 1))])
+        ys, x = _fan_out(x, [self.b0, self.b1, self.b2])
+        return _cat(ys + [self.b3(F.avg_pool2d(x, 3, 1, 1))])
 
 
 class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
@@ -81,7 +114,8 @@ class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
                                 ConvBN(192, 192, (7, 1), padding=(3, 0)), ConvBN(192, 192, 3, stride=2))
 
     def forward(self, x):
-        return _cat([self.b0(x), self.b1(x), F.max_pool2d(x, 3, 2)])
+        ys, x = _fan_out(x, [self.b0, self.b1])
+        return _cat(ys + [F.max_pool2d(x, 3, 2)])
 
 
 class InceptionE(nn.Module):          # Mixed_7b/7c
@@ -97,9 +131,8 @@ class InceptionE(nn.Module):          # Mixed_7b/7c
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
-        y1 = self.b1(x)
-        y2 = self.b2(x)
-        return _cat([self.b0(x), self.b1a(y1), self.b1b(y1), self.b2a(y2), self.b2b(y2),
+        (y0, y1, y2), x = _fan_out(x, [self.b0, self.b1, self.b2])
+        return _cat([y0, self.b1a(y1), self.b1b(y1), self.b2a(y2), self.b2b(y2),
                      self.b3(F.avg_pool2d(x, 3, 1, 1))])
 
 
