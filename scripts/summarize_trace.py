@@ -31,15 +31,12 @@ def cat(n):
     return n[:60]
 
 
-def main(path, steps_back=1):
+def main(path, total_steps=7):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     idx = [i for i, r in enumerate(rows) if 'sgd_momentum' in r['Kernel_Name'] or 'adam_apply' in r['Kernel_Name']]
-    # launches per step = count in the last two identical-gap groups; assume >= 2 steps traced
-    per_step = 1
-    gaps = [b - a for a, b in zip(idx, idx[1:])]
-    if len(gaps) >= 4 and abs(gaps[-1] - gaps[-3]) <= 2 and abs(gaps[-1] - gaps[-2]) > 2:
-        per_step = 2
+    # shard-apply launches per step (= buckets); total_steps = warm-up + timed steps of the traced run
+    per_step = max(1, round(len(idx) / float(total_steps)))
     a, b = idx[-1 - per_step], idx[-1]
     step = rows[a + 1:b + 1]
     agg = collections.OrderedDict()
@@ -58,4 +55,4 @@ def main(path, steps_back=1):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 7)
