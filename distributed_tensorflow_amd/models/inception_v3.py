@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct
 from ..ops.conv import Conv1x1
+from ..ops.pool import max_pool2d
 
 
 class ConvBN(nn.Module):
@@ -87,7 +88,7 @@ class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
 
     def forward(self, x):
         (y1,), x = _fan_out(x, [self.b1])
-        return _cat([self.b0(x), y1, F.max_pool2d(x, 3, 2)])
+        return _cat([self.b0(x), y1, max_pool2d(x, 3, 2)])
 
 
 class InceptionC(nn.Module):          # Mixed_6b..6e
@@ -115,7 +116,7 @@ class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
 
     def forward(self, x):
         ys, x = _fan_out(x, [self.b0, self.b1])
-        return _cat(ys + [F.max_pool2d(x, 3, 2)])
+        return _cat(ys + [max_pool2d(x, 3, 2)])
 
 
 class InceptionE(nn.Module):          # Mixed_7b/7c
@@ -176,9 +177,9 @@ class InceptionV3(nn.Module):
 
     def forward(self, x):
         x = self.Conv2d_2b_3x3(self.Conv2d_2a_3x3(self.Conv2d_1a_3x3(x)))
-        x = F.max_pool2d(x, 3, 2)
+        x = max_pool2d(x, 3, 2)
         x = self.Conv2d_4a_3x3(self.Conv2d_3b_1x1(x))
-        x = F.max_pool2d(x, 3, 2)
+        x = max_pool2d(x, 3, 2)
         x = self.Mixed_5d(self.Mixed_5c(self.Mixed_5b(x)))
         x = self.Mixed_6e(self.Mixed_6d(self.Mixed_6c(self.Mixed_6b(self.Mixed_6a(x)))))
         aux = self.AuxLogits(x) if (self.AuxLogits is not None and self.training) else None

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct
 from ..ops.conv import Conv1x1
+from ..ops.pool import max_pool2d
 
 _DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
@@ -90,7 +91,7 @@ class ResNet(nn.Module):
 
     def forward(self, x):
         x = self.bn1(self.conv1(x))
-        x = F.max_pool2d(x, 3, 2, 1)
+        x = max_pool2d(x, 3, 2, 1)           # K9: tap-index forward, gather backward
         x = self.block4(self.block3(self.block2(self.block1(x))))
         x = x.mean((2, 3))
         return self.fc(x)

@@ -522,3 +522,27 @@ def test_fork_chain_gradients_match_autograd_sum(dev, block, monkeypatch):
     assert float((g1 - g2).norm() / g2.norm()) < 0.03
     for n in p1:
         assert float((p1[n] - p2[n]).norm() / (p2[n].norm() + 1e-6)) < 0.06, n
+
+
+@pytest.mark.parametrize("shape,k,s,p", [((4, 64, 30, 30), 3, 2, 1), ((3, 64, 29, 31), 3, 2, 0), ((2, 192, 17, 17), 3, 2, 0),
+                                          ((2, 8, 7, 9), 3, 1, 1), ((2, 16, 12, 12), 2, 2, 0), ((1, 72, 5, 5), 3, 2, 1)])
+def test_maxpool_kernel_matches_reference(dev, shape, k, s, p):
+    from distributed_tensorflow_amd.ops.pool import max_pool2d
+
+    torch.manual_seed(0)
+    x = torch.randn(*shape, device=dev).to(torch.bfloat16)
+    x = (x * 4).round() / 4          # many exact ties: exercises the first-maximum rule
+    x = x.contiguous(memory_format=torch.channels_last)
+    x1 = x.clone().requires_grad_()
+    y1 = max_pool2d(x1, k, s, p)
+    x2 = x.float().requires_grad_()
+    y2 = torch.nn.functional.max_pool2d(x2, k, s, p)
+    assert y1.shape == y2.shape and y1.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y1.float(), y2, rtol=0, atol=0)
+    dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y1.backward(dy)
+    y2.backward(dy.float())
+    assert x1.grad.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(x1.grad.float(), x2.grad, rtol=1e-2, atol=1e-2)
+    # every gradient element lands somewhere: totals agree
+    assert abs(float(x1.grad.float().sum() - dy.float().sum())) <= 1e-2 * float(dy.float().abs().sum())
