@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct
 from ..ops.conv import Conv1x1
-from ..ops.pool import max_pool2d
+from ..ops.pool import avg_pool2d, max_pool2d
 
 
 class ConvBN(nn.Module):
@@ -77,7 +77,7 @@ class InceptionA(nn.Module):          # Mixed_5b/5c/5d
 
     def forward(self, x):
         ys, x = _fan_out(x, [self.b0, self.b1, self.b2])
-        return _cat(ys + [self.b3(F.avg_pool2d(x, 3, 1, 1))])
+        return _cat(ys + [self.b3(avg_pool2d(x, 3, 1, 1))])
 
 
 class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
@@ -104,7 +104,7 @@ class InceptionC(nn.Module):          # Mixed_6b..6e
 
     def forward(self, x):
         ys, x = _fan_out(x, [self.b0, self.b1, self.b2])
-        return _cat(ys + [self.b3(F.avg_pool2d(x, 3, 1, 1))])
+        return _cat(ys + [self.b3(avg_pool2d(x, 3, 1, 1))])
 
 
 class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
@@ -134,7 +134,7 @@ class InceptionE(nn.Module):          # Mixed_7b/7c
     def forward(self, x):
         (y0, y1, y2), x = _fan_out(x, [self.b0, self.b1, self.b2])
         return _cat([y0, self.b1a(y1), self.b1b(y1), self.b2a(y2), self.b2b(y2),
-                     self.b3(F.avg_pool2d(x, 3, 1, 1))])
+                     self.b3(avg_pool2d(x, 3, 1, 1))])
 
 
 class AuxHead(nn.Module):
@@ -145,7 +145,7 @@ class AuxHead(nn.Module):
         self.fc = nn.Linear(768, num_classes)
 
     def forward(self, x):
-        x = F.avg_pool2d(x, 5, 3)
+        x = avg_pool2d(x, 5, 3)
         x = self.conv1(self.conv0(x))
         return self.fc(x.mean((2, 3)))
 

@@ -103,6 +103,101 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Average pooling (Inception's 3x3/1 "pool + 1x1" branches, the aux head's 5x5/3).  Same two
+// gather shapes as above; the divisor of a window is recomputed from its coordinates.
+// include_pad: divide by the window clipped to the *padded* image (the framework default);
+// otherwise by the number of real pixels (TF 'SAME' average pooling).
+// ---------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ float avg_divisor(int oh, int ow, int H, int W, int stride, int pad, int include_pad) {
+    int h0 = oh * stride - pad, w0 = ow * stride - pad;
+    int h1 = h0 + K, w1 = w0 + K;
+    if (h1 > H + pad) h1 = H + pad;
+    if (w1 > W + pad) w1 = W + pad;
+    if (include_pad) return (float)((h1 - h0) * (w1 - w0));
+    if (h0 < 0) h0 = 0;
+    if (w0 < 0) w0 = 0;
+    if (h1 > H) h1 = H;
+    if (w1 > W) w1 = W;
+    return (float)((h1 - h0) * (w1 - w0));
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* __restrict__ x,
+                                                          unsigned short* __restrict__ y, int N, int H, int W, int C,
+                                                          int OH, int OW, int stride, int pad, int include_pad) {
+    const int C8 = C >> 3;
+    const int64_t total = (int64_t)N * OH * OW * C8;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(t % C8);
+        int64_t pix = t / C8;
+        const int ow = (int)(pix % OW);
+        pix /= OW;
+        const int oh = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        const int h0 = oh * stride - pad, w0 = ow * stride - pad;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        const unsigned short* xn = x + (int64_t)n * H * W * C + c8 * 8;
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int h = h0 + kh;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int w = w0 + kw;
+                if (w < 0 || w >= W) continue;
+                float v[8];
+                load8<DTF_BF16>(xn, ((int64_t)h * W + w) * C, v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+        }
+        const float inv = 1.f / avg_divisor<K>(oh, ow, H, W, stride, pad, include_pad);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] *= inv;
+        store8<DTF_BF16>(y, (((int64_t)n * OH + oh) * OW + ow) * C + c8 * 8, acc);
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                          unsigned short* __restrict__ dx, int N, int H, int W, int C,
+                                                          int OH, int OW, int stride, int pad, int include_pad) {
+    const int C8 = C >> 3;
+    const int64_t total = (int64_t)N * H * W * C8;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(t % C8);
+        int64_t pix = t / C8;
+        const int w = (int)(pix % W);
+        pix /= W;
+        const int h = (int)(pix % H);
+        const int n = (int)(pix / H);
+        int oh_lo = h + pad - (K - 1);
+        oh_lo = oh_lo <= 0 ? 0 : (oh_lo + stride - 1) / stride;
+        int oh_hi = (h + pad) / stride;
+        if (oh_hi > OH - 1) oh_hi = OH - 1;
+        int ow_lo = w + pad - (K - 1);
+        ow_lo = ow_lo <= 0 ? 0 : (ow_lo + stride - 1) / stride;
+        int ow_hi = (w + pad) / stride;
+        if (ow_hi > OW - 1) ow_hi = OW - 1;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const float inv = 1.f / avg_divisor<K>(oh, ow, H, W, stride, pad, include_pad);
+                float g[8];
+                load8<DTF_BF16>(dy, (((int64_t)n * OH + oh) * OW + ow) * C + c8 * 8, g);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf(g[k], inv, acc[k]);
+            }
+        store8<DTF_BF16>(dx, ((((int64_t)n * H + h) * W + w) * C) + c8 * 8, acc);
+    }
+}
+
 extern "C" {
 
 int dtf_maxpool_fwd(const void* x, void* y, void* tap, int N, int H, int W, int C, int OH, int OW, int k,
@@ -143,6 +238,34 @@ int dtf_maxpool_bwd(const void* dy, const void* tap, void* dx, int N, int H, int
         hipLaunchKernelGGL((maxpool_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, dys, ts, dxs, N, H, W, C, OH, OW, stride, pad);
     else
         return -23;
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+int dtf_avgpool(const void* in, void* out, int backward, int N, int H, int W, int C, int OH, int OW, int k, int stride,
+                int pad, int include_pad, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || N <= 0 || OH <= 0 || OW <= 0 || stride < 1 || pad < 0 || pad >= k) return -20;
+    if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return -21;
+    const int64_t items = (int64_t)N * (backward ? (int64_t)H * W : (int64_t)OH * OW) * (C / 8);
+    int64_t blocks = (items + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    const unsigned short* is = (const unsigned short*)in;
+    unsigned short* os = (unsigned short*)out;
+#define AVG(KK)                                                                                                   \
+    do {                                                                                                          \
+        if (backward)                                                                                             \
+            hipLaunchKernelGGL((avgpool_bwd_kernel<KK>), dim3((unsigned)blocks), dim3(256), 0, stream, is, os, N, \
+                               H, W, C, OH, OW, stride, pad, include_pad);                                        \
+        else                                                                                                      \
+            hipLaunchKernelGGL((avgpool_fwd_kernel<KK>), dim3((unsigned)blocks), dim3(256), 0, stream, is, os, N, \
+                               H, W, C, OH, OW, stride, pad, include_pad);                                        \
+    } while (0)
+    if (k == 3) AVG(3);
+    else if (k == 2) AVG(2);
+    else if (k == 5) AVG(5);
+    else return -23;
+#undef AVG
     DTF_CHECK_LAUNCH();
     return 0;
 }
