@@ -21,13 +21,13 @@ from ..ops.linear import FusedLinear
 
 
 class Layer(nn.Module):
-    def __init__(self, H, A, I, p):
+    def __init__(self, H, A, I, p, act="gelu_tanh"):
         super().__init__()
         self.A = A
         self.qkv = FusedLinear(H, 3 * H)
         self.attn_out = FusedLinear(H, H)
         self.attn_ln = nn.LayerNorm(H, eps=1e-12)
-        self.inter = FusedLinear(H, I, act="gelu")
+        self.inter = FusedLinear(H, I, act=act)
         self.out = FusedLinear(I, H)
         self.out_ln = nn.LayerNorm(H, eps=1e-12)
         self.p = p
@@ -44,16 +44,17 @@ class Layer(nn.Module):
 
 class Bert(nn.Module):
     def __init__(self, vocab=30522, hidden=768, layers=12, heads=12, intermediate=3072, max_pos=512,
-                 type_vocab=2, dropout=0.0):
+                 type_vocab=2, dropout=0.0, act="gelu_tanh"):
         super().__init__()
         self.hidden, self.vocab = hidden, vocab
         self.word_embeddings = nn.Embedding(vocab, hidden)
         self.position_embeddings = nn.Embedding(max_pos, hidden)
         self.token_type_embeddings = nn.Embedding(type_vocab, hidden)
         self.emb_ln = nn.LayerNorm(hidden, eps=1e-12)
-        self.layers = nn.ModuleList(Layer(hidden, heads, intermediate, dropout) for _ in range(layers))
+        # act: "gelu_tanh" is the google-research/bert definition (tanh form); "gelu" the erf form
+        self.layers = nn.ModuleList(Layer(hidden, heads, intermediate, dropout, act) for _ in range(layers))
         self.pooler = FusedLinear(hidden, hidden)
-        self.mlm_transform = FusedLinear(hidden, hidden, act="gelu")
+        self.mlm_transform = FusedLinear(hidden, hidden, act=act)
         self.mlm_ln = nn.LayerNorm(hidden, eps=1e-12)
         self.mlm_bias = nn.Parameter(torch.zeros(vocab))
         self.nsp = nn.Linear(hidden, 2)
@@ -86,8 +87,8 @@ class Bert(nn.Module):
         return mlm_logits, self.nsp(pooled)
 
 
-def build(layers=12, hidden=768, heads=12, intermediate=3072, vocab=30522, seq_len=512, **_):
-    return Bert(int(vocab), int(hidden), int(layers), int(heads), int(intermediate), max(512, int(seq_len)))
+def build(layers=12, hidden=768, heads=12, intermediate=3072, vocab=30522, seq_len=512, act="gelu_tanh", **_):
+    return Bert(int(vocab), int(hidden), int(layers), int(heads), int(intermediate), max(512, int(seq_len)), act=act)
 
 
 def prepare(model, device):

@@ -17,7 +17,8 @@ import torch.nn.functional as F
 
 from . import hip
 
-ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2}
+ACT = {"none": 0, None: 0, "relu": 1, "gelu": 2, "gelu_tanh": 3}
+_GELUS = ("gelu", "gelu_tanh")
 _declared = False
 _ws = {}
 
@@ -48,6 +49,8 @@ def linear_act_reference(x, weight, bias=None, act="none", residual=None):
         y = F.relu(y)
     elif act == "gelu":
         y = F.gelu(y)
+    elif act == "gelu_tanh":
+        y = F.gelu(y, approximate="tanh")
     if residual is not None:
         y = y + residual
     return y
@@ -85,7 +88,7 @@ class _FusedLinear(torch.autograd.Function):
         r2 = None
         if residual is not None:
             r2 = residual.reshape(-1, weight.shape[0]).contiguous()
-        y, pre = gemm_bias_act(x2, weight, bias, act, r2, save_preact=(act == "gelu"))
+        y, pre = gemm_bias_act(x2, weight, bias, act, r2, save_preact=(act in _GELUS))
         z = y if act == "relu" else pre      # relu: mask = y > 0 (fused_linear keeps relu+residual unfused)
         ctx.save_for_backward(x2, weight, z)
         ctx.act, ctx.has_bias, ctx.has_res, ctx.shape = act, bias is not None, residual is not None, shp
@@ -103,9 +106,9 @@ class _FusedLinear(torch.autograd.Function):
         lib = _lib()
         dres = dy if ctx.has_res else None
         dbias = torch.empty(N, dtype=ctx.bias_dtype, device=dy.device) if ctx.has_bias else None
-        if ctx.act in ("relu", "gelu") or ctx.has_bias:
+        if ctx.act in ("relu",) + _GELUS or ctx.has_bias:
             if N % 8 == 0:
-                need_dz = ctx.act in ("relu", "gelu")
+                need_dz = ctx.act in ("relu",) + _GELUS
                 dz = torch.empty_like(dy2) if need_dz else None
                 part = _partial(dy.device, int(lib.dtf_act_bwd_partial_floats(M, N)))
                 rc = lib.dtf_act_bwd_bias(hip.ptr(dy2), hip.ptr(z), hip.ptr(dz), hip.ptr(dbias),
@@ -121,6 +124,11 @@ class _FusedLinear(torch.autograd.Function):
                     zf = z.float()
                     dz = (dy2.float() * (0.5 * (1 + torch.erf(zf * 0.7071067811865476))
                                          + zf * torch.exp(-0.5 * zf * zf) * 0.3989422804014327)).to(dy2.dtype)
+                elif ctx.act == "gelu_tanh":
+                    zf = z.float().requires_grad_()
+                    with torch.enable_grad():
+                        (g,) = torch.autograd.grad(F.gelu(zf, approximate="tanh").sum(), zf)
+                    dz = (dy2.float() * g).to(dy2.dtype)
                 else:
                     dz = dy2
                 if dbias is not None:

@@ -40,3 +40,14 @@ for shp in shapes:
         row[tag + "_fwd_us"] = round(tf * 1e6, 1); row[tag + "_fwd_TBs"] = round(fb / tf / 1e12, 2)
         row[tag + "_bwd_us"] = round(tb * 1e6, 1); row[tag + "_bwd_TBs"] = round(bb / tb / 1e12, 2)
     print(json.dumps(row), flush=True)
+
+# calibration: what a plain streaming kernel reaches on this part (framework copy / fill / read)
+for mb in (103, 411, 1644):
+    n = mb * 1000 * 1000 // 2
+    a = torch.empty(n, device=dev, dtype=torch.bfloat16).normal_()
+    c = torch.empty_like(a)
+    tc = timeit(lambda: c.copy_(a))
+    tf = timeit(lambda: c.fill_(1.0))
+    tr = timeit(lambda: a.view(torch.int16).max())
+    print(json.dumps({"calib_MB": mb, "copy_TBs": round(2 * n * 2 / tc / 1e12, 2), "fill_TBs": round(n * 2 / tf / 1e12, 2),
+                      "read_TBs": round(n * 2 / tr / 1e12, 2)}), flush=True)

@@ -314,8 +314,8 @@ def test_gemm_identity_with_asymmetric_b(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 100, 784), (1000, 3072, 768), (8192, 768, 3072),
-                                   (77, 10, 104), (4096, 1024, 1672), (130, 264, 8)])
-@pytest.mark.parametrize("act", ["none", "relu", "gelu"])
+                                   (77, 10, 104), (4096, 1024, 1672), (130, 264, 8), (8200, 3000, 800)])
+@pytest.mark.parametrize("act", ["none", "relu", "gelu", "gelu_tanh"])
 @pytest.mark.parametrize("with_res", [False, True])
 def test_gemm_bias_act_forward(dev, M, N, K, act, with_res):
     if act == "relu" and with_res:
@@ -327,14 +327,63 @@ def test_gemm_bias_act_forward(dev, M, N, K, act, with_res):
     r = torch.randn(M, N, device=dev).to(torch.bfloat16) if with_res else None
     if N % 8 != 0 and with_res:
         pytest.skip("residual needs N % 8 == 0 alignment per row")
-    y, pre = lin.gemm_bias_act(x, w, b, act, r, save_preact=(act == "gelu"))
+    y, pre = lin.gemm_bias_act(x, w, b, act, r, save_preact=(act in ("gelu", "gelu_tanh")))
     ref = lin.linear_act_reference(x.float(), w.float(), b.float(), act, None if r is None else r.float())
     torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
     if pre is not None:
         torch.testing.assert_close(pre.float(), torch.nn.functional.linear(x.float(), w.float(), b.float()), rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("act", ["none", "relu", "gelu"])
+@pytest.mark.parametrize("K", [32, 64, 96, 128, 800, 4128, 4160])
+@pytest.mark.parametrize("M,N", [(256, 256), (300, 520), (1000, 264)])
+def test_gemm_256_tile_variant(dev, M, N, K):
+    """The 256x256 LDS-DMA kernel forced on small problems: every pipeline prologue/tail length (1, 2, 3,
+    4 K tiles), odd tile counts, the paired-staging schedule (K > 4096) and clamped edge rows."""
+    import ctypes
+
+    from distributed_tensorflow_amd.ops import hip
+
+    lin._lib()
+    set_tile = hip.declare("dtf_gemm_set_tile", [ctypes.c_int], None)
+    torch.manual_seed(0)
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=dev).to(torch.bfloat16)
+    r = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    set_tile(256)
+    try:
+        y, pre = lin.gemm_bias_act(x, w, b, "gelu_tanh", r, save_preact=True)
+        y0, _ = lin.gemm_bias_act(x, w, None, "none")
+    finally:
+        set_tile(0)
+    ref0 = x.float() @ w.float().t()
+    torch.testing.assert_close(y0.float(), ref0, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(pre.float(), ref0 + b.float(), rtol=2e-2, atol=2e-2)
+    ref = lin.linear_act_reference(x.float(), w.float(), b.float(), "gelu_tanh", r.float())
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=3e-2)
+
+
+def test_gemm_256_identity_layout(dev):
+    """A = I against an asymmetric B: catches a transposed or permuted C map in the 256 kernel."""
+    import ctypes
+
+    from distributed_tensorflow_amd.ops import hip
+
+    lin._lib()
+    set_tile = hip.declare("dtf_gemm_set_tile", [ctypes.c_int], None)
+    M = K = 512
+    N = 384
+    x = torch.eye(M, K, device=dev, dtype=torch.bfloat16)
+    w = ((torch.arange(N, device=dev).unsqueeze(1) * 3 + torch.arange(K, device=dev).unsqueeze(0)) % 251).to(torch.bfloat16)
+    set_tile(256)
+    try:
+        y, _ = lin.gemm_bias_act(x, w, None, "none")
+    finally:
+        set_tile(0)
+    assert torch.equal(y, w.t().contiguous())
+
+
+@pytest.mark.parametrize("act", ["none", "relu", "gelu", "gelu_tanh"])
 def test_fused_linear_backward(dev, act):
     torch.manual_seed(1)
     M, K, N = 512, 256, 384
