@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops.layernorm import FusedLayerNorm
 from ..ops.linear import FusedLinear
 
 
@@ -26,16 +27,17 @@ class Layer(nn.Module):
         self.A = A
         self.qkv = FusedLinear(H, 3 * H)
         self.attn_out = FusedLinear(H, H)
-        self.attn_ln = nn.LayerNorm(H, eps=1e-12)
+        self.attn_ln = FusedLayerNorm(H, eps=1e-12)
         self.inter = FusedLinear(H, I, act=act)
         self.out = FusedLinear(I, H)
-        self.out_ln = nn.LayerNorm(H, eps=1e-12)
+        self.out_ln = FusedLayerNorm(H, eps=1e-12)
         self.p = p
 
     def forward(self, x, mask):
         B, S, H = x.shape
-        qkv = self.qkv(x).view(B, S, 3, self.A, H // self.A).permute(2, 0, 3, 1, 4)
-        ctx = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=mask,
+        # unbind (not qkv[i]): its backward is one stack, not three zero-filled selects plus two adds
+        q, k, v = self.qkv(x).view(B, S, 3, self.A, H // self.A).permute(2, 0, 3, 1, 4).unbind(0)
+        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask,
                                              dropout_p=self.p if self.training else 0.0)
         ctx = ctx.transpose(1, 2).reshape(B, S, H)
         x = self.attn_ln(self.attn_out(ctx, residual=x))          # residual fused in the GEMM epilogue
@@ -50,12 +52,12 @@ class Bert(nn.Module):
         self.word_embeddings = nn.Embedding(vocab, hidden)
         self.position_embeddings = nn.Embedding(max_pos, hidden)
         self.token_type_embeddings = nn.Embedding(type_vocab, hidden)
-        self.emb_ln = nn.LayerNorm(hidden, eps=1e-12)
+        self.emb_ln = FusedLayerNorm(hidden, eps=1e-12)
         # act: "gelu_tanh" is the google-research/bert definition (tanh form); "gelu" the erf form
         self.layers = nn.ModuleList(Layer(hidden, heads, intermediate, dropout, act) for _ in range(layers))
         self.pooler = FusedLinear(hidden, hidden)
         self.mlm_transform = FusedLinear(hidden, hidden, act=act)
-        self.mlm_ln = nn.LayerNorm(hidden, eps=1e-12)
+        self.mlm_ln = FusedLayerNorm(hidden, eps=1e-12)
         self.mlm_bias = nn.Parameter(torch.zeros(vocab))
         self.nsp = nn.Linear(hidden, 2)
         self.apply(self._init)

@@ -479,14 +479,28 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(const unsigned short*
     }
 }
 
+// One block per 8 columns: 32 row lanes x 8 columns, every lane keeps up to 16 independent loads in
+// flight (the first version summed all <= 512 partial rows serially per thread: 34 us per call).
+// Fixed summation order -> bitwise reproducible bias gradients.
 template <int PDT>
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int N,
                                                               void* out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     float s = 0.f;
-    for (int j = 0; j < nblk; ++j) s += partial[(int64_t)j * N + c];
-    store1<PDT>(out, c, s);
+    if (c < N) {
+#pragma unroll 4
+        for (int j = rl; j < nblk; j += 32) s += partial[(int64_t)j * N + c];
+    }
+    // lanes with equal (lane & 7) hold the same column: fold lane bits 3..5, then the 4 waves in order
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+    __shared__ float red[4][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 8) red[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < 8 && c < N)
+        store1<PDT>(out, c, ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
 }
 
 static int force_tile = 0;       // 128 | 256 pins the tile variant (DTF_GEMM_TILE or dtf_gemm_set_tile; A/B runs)
@@ -551,10 +565,10 @@ int dtf_act_bwd_bias(const void* dy, const void* z, void* dz, void* dbias, int b
                        (int)rpb);
     if (dbias) {
         if (bias_dtype == DTF_BF16)
-            hipLaunchKernelGGL((colsum_finalize_kernel<DTF_BF16>), dim3((N + 255) / 256), dim3(256), 0, stream,
+            hipLaunchKernelGGL((colsum_finalize_kernel<DTF_BF16>), dim3((N + 7) / 8), dim3(256), 0, stream,
                                partial, (int)nb, N, dbias);
         else
-            hipLaunchKernelGGL((colsum_finalize_kernel<DTF_F32>), dim3((N + 255) / 256), dim3(256), 0, stream,
+            hipLaunchKernelGGL((colsum_finalize_kernel<DTF_F32>), dim3((N + 7) / 8), dim3(256), 0, stream,
                                partial, (int)nb, N, dbias);
     }
     DTF_CHECK_LAUNCH();

@@ -1,0 +1,249 @@
+// K10: LayerNorm forward / backward for bf16 activations on gfx950 (BERT's 25 LayerNorms; replaces
+// TF's mean / variance / batchnorm-style op chain on the worker).
+//
+// One wave per row, 16 B (8 elements) per lane per access, the whole row held in registers
+// (NCH chunks per lane, H <= 512 * NCH), so both directions are a single pass over HBM:
+//
+//   forward : read x, write y (+ mean, rstd: 8 B per row)               4 B/elem
+//   backward: read dy, x, write dx; dgamma / dbeta accumulate in the registers of the lane that
+//             owns the column, are folded per block through LDS and written as one partial row
+//             per block; a small finalize kernel adds the partial rows in fixed order
+//             (no atomics: bitwise reproducible)                          6 B/elem
+//
+// (the framework kernels take 48 us forward and 139 us backward on a [32768, 768] tensor;
+//  the byte counts above are 20 and 30 us at 5 TB/s.)
+#include "dtf_common.h"
+
+#define LN_ROWS_PER_BLOCK 4      // waves per block
+
+template <int NCH, int PDT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x, const void* __restrict__ gamma,
+                                                     const void* __restrict__ beta, unsigned short* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int64_t M, int H, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = H >> 3;
+    const float inv_h = 1.f / (float)H;
+    float g[NCH][8], b[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+        if (ch < nchunk) {
+            load8<PDT>(gamma, ch * 8, g[j]);
+            load8<PDT>(beta, ch * 8, b[j]);
+        }
+    }
+    for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK) {
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < nchunk) {
+                load8<DTF_BF16>(x, row * H + ch * 8, v[j]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += v[j][k];
+            }
+        }
+        const float mean = wave_sum(s) * inv_h;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v[j][k] -= mean; q = fmaf(v[j][k], v[j][k], q); }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_h + eps);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[j][k] = fmaf(v[j][k] * rstd, g[j][k], b[j][k]);
+                store8<DTF_BF16>(y, row * H + ch * 8, v[j]);
+            }
+        }
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+}
+
+// partial[(blockIdx.x * 2 + {0: dgamma, 1: dbeta}) * H + c]
+template <int NCH, int PDT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const void* __restrict__ gamma, unsigned short* __restrict__ dx,
+                                                     float* __restrict__ partial, int64_t M, int H) {
+    extern __shared__ float red[];                  // [3 waves][2][H] (wave 0 adds the other three in order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = H >> 3;
+    const float inv_h = 1.f / (float)H;
+    float g[NCH][8], dg[NCH][8], db[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { dg[j][k] = 0.f; db[j][k] = 0.f; g[j][k] = 0.f; }
+        if (ch < nchunk) load8<PDT>(gamma, ch * 8, g[j]);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float xh[NCH][8], d[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < nchunk) {
+                load8<DTF_BF16>(dy, row * H + ch * 8, d[j]);
+                load8<DTF_BF16>(x, row * H + ch * 8, xh[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float xn = (xh[j][k] - mean) * rstd;
+                    const float dyv = d[j][k];
+                    dg[j][k] = fmaf(dyv, xn, dg[j][k]);
+                    db[j][k] += dyv;
+                    const float gd = dyv * g[j][k];
+                    s1 += gd;
+                    s2 = fmaf(gd, xn, s2);
+                    xh[j][k] = xn;
+                    d[j][k] = gd;
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_h, c2 = wave_sum(s2) * inv_h;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[j][k] = rstd * (d[j][k] - c1 - xh[j][k] * c2);
+                store8<DTF_BF16>(dx, row * H + ch * 8, d[j]);
+            }
+        }
+    }
+    // fold the four waves of the block in fixed order: waves 1..3 park their sums in LDS, wave 0 adds
+    if (wave > 0) {
+        float* r = red + (size_t)(wave - 1) * 2 * H;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { r[ch * 8 + k] = dg[j][k]; r[H + ch * 8 + k] = db[j][k]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* p = partial + (int64_t)blockIdx.x * 2 * H;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int c = ch * 8 + k;
+                    p[c] = ((dg[j][k] + red[c]) + red[2 * H + c]) + red[4 * H + c];
+                    p[H + c] = ((db[j][k] + red[H + c]) + red[3 * H + c]) + red[5 * H + c];
+                }
+            }
+        }
+    }
+}
+
+// columns 0..H-1 -> dgamma, H..2H-1 -> dbeta; one block per 8 columns, 32 row lanes
+template <int PDT>
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partial, int nblk, int H,
+                                                          void* dgamma, void* dbeta) {
+    const int cl = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;          // column of the [nblk][2H] partial matrix
+    const int W = 2 * H;
+    float s = 0.f;
+    if (c < W) {
+#pragma unroll 4
+        for (int j = rl; j < nblk; j += 32) s += partial[(int64_t)j * W + c];
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+    __shared__ float fr[4][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 8) fr[wave][lane] = s;
+    __syncthreads();
+    if (threadIdx.x < 8 && c < W) {
+        const float t = ((fr[0][threadIdx.x] + fr[1][threadIdx.x]) + fr[2][threadIdx.x]) + fr[3][threadIdx.x];
+        if (c < H) store1<PDT>(dgamma, c, t);
+        else store1<PDT>(dbeta, c - H, t);
+    }
+}
+
+static inline int ln_blocks(int64_t M) {
+    int64_t b = (M + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" {
+
+int64_t dtf_ln_partial_floats(int64_t M, int H) { return (int64_t)ln_blocks(M) * 2 * H; }
+
+int dtf_ln_fwd(const void* x, const void* gamma, const void* beta, int param_dtype, void* y, float* mean, float* rstd,
+               int64_t M, int H, float eps, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (M <= 0) return 0;
+    if (H <= 0 || (H & 7) || H > 4096) return -50;
+    const int nb = ln_blocks(M);
+    const unsigned short* xs = (const unsigned short*)x;
+    unsigned short* ys = (unsigned short*)y;
+#define LNF(N, P) hipLaunchKernelGGL((ln_fwd_kernel<N, P>), dim3(nb), dim3(256), 0, stream, xs, gamma, beta, ys, mean, rstd, M, H, eps)
+#define LNF_D(N) do { if (param_dtype == DTF_BF16) LNF(N, DTF_BF16); else LNF(N, DTF_F32); } while (0)
+    if (H <= 512) LNF_D(1);
+    else if (H <= 1024) LNF_D(2);
+    else if (H <= 2048) LNF_D(4);
+    else LNF_D(8);
+#undef LNF_D
+#undef LNF
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+int dtf_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, int param_dtype,
+               void* dx, void* dgamma, void* dbeta, float* partial, int64_t M, int H, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (M <= 0) return 0;
+    if (H <= 0 || (H & 7) || H > 4096) return -50;
+    const int nb = ln_blocks(M);
+    const size_t lds = (size_t)3 * 2 * H * sizeof(float);      // <= 96 KB at H = 4096
+    const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x;
+    unsigned short* dxs = (unsigned short*)dx;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)ln_bwd_kernel<8, DTF_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        hipFuncSetAttribute((const void*)ln_bwd_kernel<8, DTF_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        attr_set = true;
+    }
+#define LNB(N, P) hipLaunchKernelGGL((ln_bwd_kernel<N, P>), dim3(nb), dim3(256), lds, stream, dys, xs, mean, rstd, gamma, dxs, partial, M, H)
+#define LNB_D(N) do { if (param_dtype == DTF_BF16) LNB(N, DTF_BF16); else LNB(N, DTF_F32); } while (0)
+    if (H <= 512) LNB_D(1);
+    else if (H <= 1024) LNB_D(2);
+    else if (H <= 2048) LNB_D(4);
+    else LNB_D(8);
+#undef LNB_D
+#undef LNB
+    const int fgrid = (2 * H + 7) / 8;
+    if (param_dtype == DTF_BF16)
+        hipLaunchKernelGGL((ln_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nb, H, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL((ln_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, H, dgamma, dbeta);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -618,3 +618,33 @@ def test_avgpool_kernel_matches_reference(dev, shape, k, s, p, include_pad):
     y2.backward(dy.float().cpu().contiguous())
     assert x1.grad.is_contiguous(memory_format=torch.channels_last)
     torch.testing.assert_close(x1.grad.float().cpu(), x2.grad, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("pdt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(1000, 768), (64, 8), (300, 1024), (33, 2048), (17, 4096), (4, 130, 768), (5000, 264)])
+def test_layernorm_kernel_matches_reference(dev, shape, pdt):
+    from distributed_tensorflow_amd.ops import layernorm as ln
+
+    torch.manual_seed(0)
+    H = shape[-1]
+    x = (torch.randn(*shape, device=dev) * 2 + 0.5).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(H, device=dev)).to(pdt)
+    b = (0.1 * torch.randn(H, device=dev)).to(pdt)
+    dy = torch.randn(*shape, device=dev).to(torch.bfloat16)
+    x1, w1, b1 = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    assert ln.kernel_eligible(x1, w1, b1)
+    y1 = ln.layer_norm(x1, w1, b1, 1e-12)
+    y1.backward(dy)
+    x2, w2, b2 = x.float().requires_grad_(), w.float().clone().requires_grad_(), b.float().clone().requires_grad_()
+    y2 = torch.nn.functional.layer_norm(x2, (H,), w2, b2, 1e-12)
+    y2.backward(dy.float())
+    torch.testing.assert_close(y1.float(), y2, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(x1.grad.float(), x2.grad, rtol=2e-2, atol=2e-2)
+    rows = x.numel() // H
+    tol = 0.02 * rows ** 0.5 + 0.05 if pdt == torch.bfloat16 else 1e-2 * rows ** 0.5
+    torch.testing.assert_close(w1.grad.float(), w2.grad, rtol=2e-2, atol=tol)
+    torch.testing.assert_close(b1.grad.float(), b2.grad, rtol=2e-2, atol=tol)
+    # bitwise reproducible
+    x3, w3, b3 = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ln.layer_norm(x3, w3, b3, 1e-12).backward(dy)
+    assert torch.equal(x3.grad, x1.grad) and torch.equal(w3.grad, w1.grad) and torch.equal(b3.grad, b1.grad)
