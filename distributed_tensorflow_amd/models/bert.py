@@ -36,12 +36,15 @@ class Layer(nn.Module):
     def forward(self, x, mask):
         B, S, H = x.shape
         # unbind (not qkv[i]): its backward is one stack, not three zero-filled selects plus two adds
-        q, k, v = self.qkv(x).view(B, S, 3, self.A, H // self.A).permute(2, 0, 3, 1, 4).unbind(0)
+        # x feeds the projection and the residual: the fork sums both gradients inside the dX GEMM
+        qkv, x = self.qkv.forward_fork(x, own_skip_grad=True)
+        q, k, v = qkv.view(B, S, 3, self.A, H // self.A).permute(2, 0, 3, 1, 4).unbind(0)
         ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask,
                                              dropout_p=self.p if self.training else 0.0)
         ctx = ctx.transpose(1, 2).reshape(B, S, H)
         x = self.attn_ln(self.attn_out(ctx, residual=x))          # residual fused in the GEMM epilogue
-        return self.out_ln(self.out(self.inter(x), residual=x))
+        h, x = self.inter.forward_fork(x, own_skip_grad=True)
+        return self.out_ln(self.out(h, residual=x))
 
 
 class Bert(nn.Module):

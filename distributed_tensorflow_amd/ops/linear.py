@@ -31,6 +31,8 @@ def _lib():
         hip.declare("dtf_gemm_bias_act", [P, P, P, I, P, P, P, I, I, I, I, P])
         hip.declare("dtf_act_bwd_partial_floats", [L, I], L)
         hip.declare("dtf_act_bwd_bias", [P, P, P, P, I, P, L, I, I, P])
+        hip.declare("dtf_gemm_tn_workspace", [I, I, I], L)
+        hip.declare("dtf_gemm_tn", [P, P, P, I, P, I, I, I, P])
         _declared = True
     return lib
 
@@ -78,9 +80,43 @@ def gemm_bias_act(x2, weight, bias, act, residual=None, save_preact=False):
     return y, pre
 
 
+_tn_ws = {}
+_TN_DISABLED = _os.environ.get("DTF_GEMM_TN", "1") == "0"        # A/B switch
+
+
+def gemm_tn_eligible(a, b):
+    return (not _TN_DISABLED and a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2
+            and b.dim() == 2 and a.shape[0] == b.shape[0] and a.shape[0] % 32 == 0 and a.shape[0] >= 1024
+            and a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and a.is_contiguous() and b.is_contiguous())
+
+
+def gemm_tn(a, b, out_dtype=torch.bfloat16):
+    """``a.T @ b`` for row-major ``a [M, N]``, ``b [M, K]`` with the reduction over the rows (kernel K6T):
+    the weight gradient ``dW = dZ^T X`` of a Linear layer / 1x1 convolution."""
+    M, N = a.shape
+    K = b.shape[1]
+    lib = _lib()
+    n = int(lib.dtf_gemm_tn_workspace(M, N, K))
+    ws = _tn_ws.get(a.device)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=a.device)
+        _tn_ws[a.device] = ws
+    out = torch.empty(N, K, dtype=out_dtype, device=a.device)
+    rc = lib.dtf_gemm_tn(hip.ptr(a), hip.ptr(b), hip.ptr(out), hip.dt(out), hip.ptr(ws), M, N, K, hip.stream())
+    hip.check(rc, "dtf_gemm_tn")
+    return out
+
+
 class _FusedLinear(torch.autograd.Function):
+    """``fork=True`` also returns a pass-through alias of ``x`` for a second consumer (the residual branch
+    of a transformer block): the two gradients of ``x`` are then summed by the dX GEMM itself
+    (``dX = dZ . W + dSkip``, beta = 1) instead of a separate elementwise add.  ``own=True`` lets the GEMM
+    accumulate in place into the incoming ``dSkip`` buffer -- only valid when nobody else reads that
+    gradient tensor afterwards (see ``ops/conv.py``; true for the residual epilogue of a later
+    ``FusedLinear`` / K10 LayerNorm chain, whose gradient is a fresh tensor consumed in stream order)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act):
+    def forward(ctx, x, weight, bias, residual, act, fork=False, own=False):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
@@ -93,11 +129,16 @@ class _FusedLinear(torch.autograd.Function):
         ctx.save_for_backward(x2, weight, z)
         ctx.act, ctx.has_bias, ctx.has_res, ctx.shape = act, bias is not None, residual is not None, shp
         ctx.bias_dtype = bias.dtype if bias is not None else None
+        ctx.fork, ctx.own = fork, own
+        if fork:
+            return y.view(*shp[:-1], weight.shape[0]), x.view_as(x)
         return y.view(*shp[:-1], weight.shape[0])
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         x2, weight, z = ctx.saved_tensors
+        if dy is None:            # only the pass-through was used
+            return dskip, None, None, None, None, None, None
         N = weight.shape[0]
         dy2 = dy.reshape(-1, N)
         if not dy2.is_contiguous():
@@ -135,9 +176,23 @@ class _FusedLinear(torch.autograd.Function):
                     dbias = dz.float().sum(0).to(ctx.bias_dtype)
         else:
             dz = dy2
-        dx = torch.matmul(dz, weight).view(ctx.shape) if ctx.needs_input_grad[0] else None
-        dw = torch.matmul(dz.t(), x2) if ctx.needs_input_grad[1] else None
-        return dx, dw, dbias, dres, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if dskip is None:
+                dx = torch.matmul(dz, weight).view(ctx.shape)
+            else:
+                ds2 = dskip.reshape(-1, weight.shape[1])
+                if ctx.own and ds2.is_contiguous() and ds2.data_ptr() == dskip.data_ptr():
+                    dx = ds2.addmm_(dz, weight).view(ctx.shape)
+                else:
+                    dx = torch.addmm(ds2, dz, weight).view(ctx.shape)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if gemm_tn_eligible(dz, x2) and weight.dtype == torch.bfloat16:
+                dw = gemm_tn(dz, x2)                    # K6T: transposed-operand MFMA GEMM, split over M
+            else:
+                dw = torch.matmul(dz.t(), x2)
+        return dx, dw, dbias, dres, None, None, None
 
 
 def fused_linear(x, weight, bias=None, act="none", residual=None):
@@ -145,6 +200,14 @@ def fused_linear(x, weight, bias=None, act="none", residual=None):
     if not kernel_eligible(x, weight) or (act == "relu" and residual is not None):
         return linear_act_reference(x, weight, bias, act, residual)
     return _FusedLinear.apply(x, weight, bias, residual, act)
+
+
+def fused_linear_fork(x, weight, bias=None, act="none", own_skip_grad=False):
+    """-> ``(fused_linear(x), x')`` with ``x'`` an alias of ``x`` for the residual branch."""
+    if (not kernel_eligible(x, weight) or not torch.is_grad_enabled() or not x.requires_grad
+            or _os.environ.get("DTF_LINEAR_FORK", "1") == "0"):
+        return fused_linear(x, weight, bias, act), x
+    return _FusedLinear.apply(x, weight, bias, None, act, True, own_skip_grad)
 
 
 class FusedLinear(nn.Linear):
@@ -156,6 +219,9 @@ class FusedLinear(nn.Linear):
 
     def forward(self, x, residual=None):
         return fused_linear(x, self.weight, self.bias, self.act, residual)
+
+    def forward_fork(self, x, own_skip_grad=False):
+        return fused_linear_fork(x, self.weight, self.bias, self.act, own_skip_grad)
 
     def extra_repr(self):
         return super().extra_repr() + ", act=%s" % self.act

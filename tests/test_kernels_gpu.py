@@ -648,3 +648,53 @@ def test_layernorm_kernel_matches_reference(dev, shape, pdt):
     x3, w3, b3 = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
     ln.layer_norm(x3, w3, b3, 1e-12).backward(dy)
     assert torch.equal(x3.grad, x1.grad) and torch.equal(w3.grad, w1.grad) and torch.equal(b3.grad, b1.grad)
+
+
+@pytest.mark.parametrize("own", [False, True])
+def test_fused_linear_fork_sums_residual_gradient(dev, own):
+    torch.manual_seed(0)
+    layer = lin.FusedLinear(256, 384, act="gelu_tanh").to(dev).to(torch.bfloat16)
+    x0 = torch.randn(4, 64, 256, device=dev).to(torch.bfloat16)
+    dy = torch.randn(4, 64, 384, device=dev).to(torch.bfloat16)
+    ds = torch.randn_like(x0)
+    xl = x0.clone().requires_grad_()
+    y1, skip = layer.forward_fork(xl * 1.0, own_skip_grad=own)
+    torch.autograd.backward([y1, skip], [dy, ds.clone()])
+    x2 = x0.clone().requires_grad_()
+    y2 = layer(x2)
+    g_w = layer.weight.grad.clone()
+    layer.weight.grad = None
+    torch.autograd.backward([y2, x2 * 1.0], [dy, ds.clone()])
+    torch.testing.assert_close(y1.float(), y2.float(), rtol=0, atol=0)
+    torch.testing.assert_close(xl.grad.float(), x2.grad.float(), rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(g_w.float(), layer.weight.grad.float(), rtol=0, atol=0)
+
+
+def test_gemm_tn_identity_layout(dev):
+    """A = I: C = A^T B must reproduce an asymmetric B exactly (catches transposed / permuted fragment maps)."""
+    M = N = 1024
+    K = 520
+    a = torch.eye(M, N, device=dev, dtype=torch.bfloat16)
+    b = ((torch.arange(M, device=dev).unsqueeze(1) * 3 + torch.arange(K, device=dev).unsqueeze(0)) % 251).to(torch.bfloat16)
+    assert lin.gemm_tn_eligible(a, b)
+    c = lin.gemm_tn(a, b)
+    assert torch.equal(c, b)
+    # and a shifted one-hot: A[m, n] = 1 iff n == (m + 5) % N  ->  C[n] = B[(n - 5) % M]
+    a2 = torch.roll(a, 5, dims=1).contiguous()
+    c2 = lin.gemm_tn(a2, b)
+    assert torch.equal(c2, torch.roll(b, 5, dims=0))
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (1024, 264, 520), (32768, 3072, 768), (1056, 8, 8), (2048, 256, 256),
+                                   (12544, 2048, 512), (1120, 304, 1000)])
+def test_gemm_tn_matches_reference(dev, M, N, K):
+    torch.manual_seed(0)
+    a = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    b = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    assert lin.gemm_tn_eligible(a, b)
+    c = lin.gemm_tn(a, b, out_dtype=torch.float32)
+    ref = a.float().t() @ b.float()
+    torch.testing.assert_close(c, ref, rtol=1e-3, atol=1e-2 * M ** 0.5 / 8)
+    c16 = lin.gemm_tn(a, b)
+    assert torch.equal(c16, c.to(torch.bfloat16))
+    assert torch.equal(lin.gemm_tn(a, b, out_dtype=torch.float32), c)      # deterministic
