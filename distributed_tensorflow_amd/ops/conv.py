@@ -22,8 +22,25 @@ import torch.nn.functional as F
 
 _MM_BWD_DATA_MIN_CIN = 128
 _MM_FWD_MIN_CIN = 1024
+_TN_WRW_MIN_C = 256          # K6T weight gradient when min(Cin, Cout) >= this (narrower layers waste its 256^2 tile)
+_TN_WRW = os.environ.get("DTF_CONV1X1_TN", "1") != "0"
 _ENABLED = os.environ.get("DTF_CONV1X1_MM", "1") != "0"      # A/B switch: 0 = everything through MIOpen
 _FORK = os.environ.get("DTF_CONV1X1_FORK", "1") != "0"        # A/B switch: 0 = autograd sums the shortcut grad
+
+
+def _wrw(dy, x, weight):
+    """dW of a 1x1 stride-1 convolution: K6T (``dY^T . X`` with the pixels as reduction rows, no zero-fill /
+    cast passes around it) for wide layers, MIOpen otherwise."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if _TN_WRW and min(cin, cout) >= _TN_WRW_MIN_C:
+        from .linear import gemm_tn, gemm_tn_eligible
+
+        dy2, x2 = _rows(dy), _rows(x)
+        if gemm_tn_eligible(dy2, x2) and weight.dtype == torch.bfloat16:
+            return gemm_tn(dy2, x2).view(cout, cin, 1, 1)
+    _, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
+                                                   [0, 0], 1, [False, True, False])
+    return dw
 
 
 def _rows(x):
@@ -54,12 +71,11 @@ class _Conv1x1Fn(torch.autograd.Function):
             N, _, H, W = x.shape
             dx = torch.matmul(_rows(dy), weight.reshape(cout, cin)).view(N, H, W, cin).permute(0, 3, 1, 2)
             need_dx = False
-        if need_dx or need_dw:
-            gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
-                                                            [0, 0], 1, [need_dx, need_dw, False])
-            if need_dx:
-                dx = gx
-            dw = gw if need_dw else None
+        if need_dx:
+            dx, _, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
+                                                           [0, 0], 1, [True, False, False])
+        if need_dw:
+            dw = _wrw(dy, x, weight)
         return dx, dw
 
 
@@ -109,8 +125,7 @@ class _Conv1x1ForkFn(torch.autograd.Function):
                 dx2 = _rows(dskip).addmm_(_rows(dy), w2) if ctx.own else torch.addmm(_rows(dskip), _rows(dy), w2)
             dx = dx2.view(N, H, W, cin).permute(0, 3, 1, 2)
         if need_dw:
-            _, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
-                                                           [0, 0], 1, [False, True, False])
+            dw = _wrw(dy, x, weight)
         return dx, dw, None
 
 
