@@ -21,6 +21,22 @@ from ..ops.layernorm import FusedLayerNorm
 from ..ops.linear import FusedLinear
 
 
+class _SplitQKV(torch.autograd.Function):
+    """Packed projection output ``[B, S, 3, A, D]`` -> q, k, v views ``[B, A, S, D]`` for the attention
+    kernel.  Backward gathers dq, dk, dv straight into the packed layout with one copy kernel; plain
+    autograd stacks them as ``[3, B, A, S, D]`` and the next op then re-copies that into token-major
+    order (two passes over the 3H-wide tensor per layer: 276 us at batch 64)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        return torch.stack([dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)], dim=2)
+
+
 class Layer(nn.Module):
     def __init__(self, H, A, I, p, act="gelu_tanh"):
         super().__init__()
@@ -35,10 +51,9 @@ class Layer(nn.Module):
 
     def forward(self, x, mask):
         B, S, H = x.shape
-        # unbind (not qkv[i]): its backward is one stack, not three zero-filled selects plus two adds
         # x feeds the projection and the residual: the fork sums both gradients inside the dX GEMM
         qkv, x = self.qkv.forward_fork(x, own_skip_grad=True)
-        q, k, v = qkv.view(B, S, 3, self.A, H // self.A).permute(2, 0, 3, 1, 4).unbind(0)
+        q, k, v = _SplitQKV.apply(qkv.view(B, S, 3, self.A, H // self.A))
         ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask,
                                              dropout_p=self.p if self.training else 0.0)
         ctx = ctx.transpose(1, 2).reshape(B, S, H)
