@@ -86,7 +86,8 @@ def main():
         a.batch = {"inception_v3": 128, "inception3": 128, "bert": 64, "bert_base": 64, "wide_deep": 16384,
                    "mnist_mlp": 256, "mnist": 256}.get(key, 256)
     unit = {"bert": "sequences/sec", "bert_base": "sequences/sec", "wide_deep": "examples/sec"}.get(key, "images/sec")
-    model = mod.prepare(mod.build(**kw), dev)
+    model = mod.build(**kw)
+    model = mod.prepare(model, dev) if hasattr(mod, "prepare") else model.to(dev)
     model.train()
     opt = mod.default_optimizer()
     ps = ShardedPS(list(model.named_parameters()), comm, opt, bucket_mb=a.bucket_mb,
