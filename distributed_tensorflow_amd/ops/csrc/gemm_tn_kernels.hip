@@ -28,7 +28,7 @@ typedef __attribute__((address_space(3))) void tn_lds_void;
 typedef const __attribute__((address_space(1))) void tn_glb_void;
 
 struct TnArgs {
-    const unsigned short* A; const unsigned short* B; float* slab;
+    const unsigned short* A; const unsigned short* B; float* slab; float* bias_slab;
     int M, N, K; int ntn, ntk, splits, m_per_split;
 };
 
@@ -52,6 +52,10 @@ __device__ __forceinline__ tn_s16x4 tn_tr_read_2k(unsigned addr) {
     return v;
 }
 
+// BIAS: also produce the column sums of A (the bias gradient sum_m dZ[m, n]) -- the waves of the first
+// column of k tiles multiply their A fragments by an all-ones B fragment (8 extra MFMAs per K step for
+// one wave in four of one block in ntk), which saves the separate pass over dZ.
+template <bool BIAS>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,6 +100,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bacc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = BIAS && wc == 0 && tk == 0;
+    tn_s16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;          // bf16 1.0
 
     // transposed-read addressing: lane = 16 g + 4 q + p supplies row (8 g + 4 h + q), columns 4p .. 4p+3 of
     // the fragment's 16-column chunk c; byte = row * 512 + ((c ^ sx) << 5) + 8 p, sx = q | (g & 1) << 2
@@ -158,6 +169,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        if (BIAS && do_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, bacc[i], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         if (wr == 0) TN_WAIT_NEXT(t);
         __builtin_amdgcn_sched_barrier(0);
@@ -182,6 +197,16 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
                 if (kc < a.K) out[(int64_t)n * a.K + kc] = acc[i][j][r];
             }
         }
+    if (BIAS && do_bias && fr == 0) {        // every column of bacc holds the row sums; column 0 stores them
+        float* bo = a.bias_slab + (int64_t)split * a.N;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wr * 128 + i * 16 + g * 4 + r;
+                if (n < a.N) bo[n] = bacc[i][r];
+            }
+    }
 }
 
 // out[i] = sum_s slab[s][i] (fixed order), one rounding; 4 elements per thread
@@ -217,28 +242,34 @@ static inline void tn_plan(int M, int N, int K, int* ntn, int* ntk, int* splits,
 
 extern "C" {
 
-// fp32 workspace (floats) for dtf_gemm_tn
+// fp32 workspace (floats) for dtf_gemm_tn: the dW slabs, then the bias slabs
 int64_t dtf_gemm_tn_workspace(int M, int N, int K) {
     int ntn, ntk, splits, mps;
     tn_plan(M, N, K, &ntn, &ntk, &splits, &mps);
-    return (int64_t)splits * N * K;
+    return (int64_t)splits * N * K + (int64_t)splits * N;
 }
 
 // C[N,K] = A[M,N]^T . B[M,K]; A, B bf16 row-major; C bf16 (out_dtype 1) or fp32 (0)
-int dtf_gemm_tn(const void* A, const void* B, void* C, int out_dtype, float* workspace, int M, int N, int K,
-                hipStream_t stream) {
+// dbias (optional, [N], bias_dtype): column sums of A
+int dtf_gemm_tn(const void* A, const void* B, void* C, int out_dtype, void* dbias, int bias_dtype, float* workspace,
+                int M, int N, int K, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if ((M & 31) || (N & 7) || (K & 7)) return -60;
     if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)workspace)) & 15) return -16;
-    TnArgs a{(const unsigned short*)A, (const unsigned short*)B, workspace, M, N, K, 0, 0, 0, 0};
+    TnArgs a{(const unsigned short*)A, (const unsigned short*)B, workspace, nullptr, M, N, K, 0, 0, 0, 0};
     tn_plan(M, N, K, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
+    a.bias_slab = workspace + (int64_t)a.splits * N * K;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
+    if (dbias)
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
     const int64_t n4 = (int64_t)N * K / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -248,6 +279,15 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int out_dtype, float* wor
     else
         hipLaunchKernelGGL((tn_reduce_kernel<DTF_F32>), dim3((unsigned)blocks), dim3(256), 0, stream, workspace, a.splits,
                            n4, (int64_t)N * K, C);
+    if (dbias) {
+        const int64_t b4 = N / 4;
+        if (bias_dtype == DTF_BF16)
+            hipLaunchKernelGGL((tn_reduce_kernel<DTF_BF16>), dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, stream,
+                               a.bias_slab, a.splits, b4, (int64_t)N, dbias);
+        else
+            hipLaunchKernelGGL((tn_reduce_kernel<DTF_F32>), dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, stream,
+                               a.bias_slab, a.splits, b4, (int64_t)N, dbias);
+    }
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -32,7 +32,7 @@ def _lib():
         hip.declare("dtf_act_bwd_partial_floats", [L, I], L)
         hip.declare("dtf_act_bwd_bias", [P, P, P, P, I, P, L, I, I, P])
         hip.declare("dtf_gemm_tn_workspace", [I, I, I], L)
-        hip.declare("dtf_gemm_tn", [P, P, P, I, P, I, I, I, P])
+        hip.declare("dtf_gemm_tn", [P, P, P, I, P, I, P, I, I, I, P])
         _declared = True
     return lib
 
@@ -82,6 +82,7 @@ def gemm_bias_act(x2, weight, bias, act, residual=None, save_preact=False):
 
 _tn_ws = {}
 _TN_DISABLED = _os.environ.get("DTF_GEMM_TN", "1") == "0"        # A/B switch
+_TN_FUSE_BIAS = _os.environ.get("DTF_TN_FUSE_BIAS", "1") != "0"  # A/B switch
 
 
 def gemm_tn_eligible(a, b):
@@ -90,9 +91,10 @@ def gemm_tn_eligible(a, b):
             and a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and a.is_contiguous() and b.is_contiguous())
 
 
-def gemm_tn(a, b, out_dtype=torch.bfloat16):
+def gemm_tn(a, b, out_dtype=torch.bfloat16, colsum_dtype=None):
     """``a.T @ b`` for row-major ``a [M, N]``, ``b [M, K]`` with the reduction over the rows (kernel K6T):
-    the weight gradient ``dW = dZ^T X`` of a Linear layer / 1x1 convolution."""
+    the weight gradient ``dW = dZ^T X`` of a Linear layer / 1x1 convolution.  With ``colsum_dtype`` also
+    returns ``a.sum(0)`` (the bias gradient) computed inside the same kernel: ``(dW, dbias)``."""
     M, N = a.shape
     K = b.shape[1]
     lib = _lib()
@@ -102,9 +104,11 @@ def gemm_tn(a, b, out_dtype=torch.bfloat16):
         ws = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=a.device)
         _tn_ws[a.device] = ws
     out = torch.empty(N, K, dtype=out_dtype, device=a.device)
-    rc = lib.dtf_gemm_tn(hip.ptr(a), hip.ptr(b), hip.ptr(out), hip.dt(out), hip.ptr(ws), M, N, K, hip.stream())
+    cs = torch.empty(N, dtype=colsum_dtype, device=a.device) if colsum_dtype is not None else None
+    rc = lib.dtf_gemm_tn(hip.ptr(a), hip.ptr(b), hip.ptr(out), hip.dt(out), hip.ptr(cs),
+                         hip.dt(cs) if cs is not None else 0, hip.ptr(ws), M, N, K, hip.stream())
     hip.check(rc, "dtf_gemm_tn")
-    return out
+    return out if cs is None else (out, cs)
 
 
 class _FusedLinear(torch.autograd.Function):
@@ -147,7 +151,12 @@ class _FusedLinear(torch.autograd.Function):
         lib = _lib()
         dres = dy if ctx.has_res else None
         dbias = torch.empty(N, dtype=ctx.bias_dtype, device=dy.device) if ctx.has_bias else None
-        if ctx.act in ("relu",) + _GELUS or ctx.has_bias:
+        # no activation: dZ = dY and the bias gradient rides in the weight-gradient kernel (K6T)
+        fuse_dbias = (_TN_FUSE_BIAS and ctx.act in ("none", None) and ctx.has_bias and ctx.needs_input_grad[1] and N % 8 == 0
+                      and weight.dtype == torch.bfloat16 and gemm_tn_eligible(dy2, x2))
+        if fuse_dbias:
+            dz = dy2
+        elif ctx.act in ("relu",) + _GELUS or ctx.has_bias:
             if N % 8 == 0:
                 need_dz = ctx.act in ("relu",) + _GELUS
                 dz = torch.empty_like(dy2) if need_dz else None
@@ -187,7 +196,9 @@ class _FusedLinear(torch.autograd.Function):
                 else:
                     dx = torch.addmm(ds2, dz, weight).view(ctx.shape)
         dw = None
-        if ctx.needs_input_grad[1]:
+        if fuse_dbias:
+            dw, dbias = gemm_tn(dz, x2, colsum_dtype=ctx.bias_dtype)
+        elif ctx.needs_input_grad[1]:
             if gemm_tn_eligible(dz, x2) and weight.dtype == torch.bfloat16:
                 dw = gemm_tn(dz, x2)                    # K6T: transposed-operand MFMA GEMM, split over M
             else:

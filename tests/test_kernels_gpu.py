@@ -698,3 +698,6 @@ def test_gemm_tn_matches_reference(dev, M, N, K):
     c16 = lin.gemm_tn(a, b)
     assert torch.equal(c16, c.to(torch.bfloat16))
     assert torch.equal(lin.gemm_tn(a, b, out_dtype=torch.float32), c)      # deterministic
+    c2, cs = lin.gemm_tn(a, b, out_dtype=torch.float32, colsum_dtype=torch.float32)
+    assert torch.equal(c2, c)
+    torch.testing.assert_close(cs, a.float().sum(0), rtol=1e-3, atol=1e-2 * M ** 0.5 / 8)
