@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops.batchnorm import FusedBatchNormAct
+from ..ops.batchnorm import FusedBatchNormAct, bn_act_concat
 from ..ops.conv import Conv1x1
 from ..ops.pool import avg_pool2d, max_pool2d
 
@@ -40,31 +40,29 @@ class ConvBN(nn.Module):
         return self.bn(self.conv(x)), x
 
 
-def _head(branch):
-    return branch[0] if isinstance(branch, nn.Sequential) else branch
+def _conv_fork(m, x):
+    """Convolution of ConvBN ``m`` only (its BN runs inside the block's concat) + the input fork."""
+    if isinstance(m.conv, Conv1x1):
+        return m.conv.forward_fork(x, own_skip_grad=True)
+    return m.conv(x), x
 
 
-def _tail(branch, y):
-    if isinstance(branch, nn.Sequential):
-        for m in list(branch)[1:]:
-            y = m(y)
-    return y
+def _branch(branch, x):
+    """Run a branch up to -- not including -- its last BatchNorm: -> ((conv_out, bn), x').  The 1x1 head
+    forks ``x`` so the branch gradients of the block input are summed inside the dX GEMMs; the last BN of
+    every branch runs in :func:`bn_act_concat`, which writes straight into the block's output."""
+    if isinstance(branch, ConvBN):
+        y, x = _conv_fork(branch, x)
+        return (y, branch.bn), x
+    mods = list(branch)
+    h, x = mods[0].forward_fork(x)
+    for m in mods[1:-1]:
+        h = m(h)
+    return (mods[-1].conv(h), mods[-1].bn), x
 
 
-def _fan_out(x, branches):
-    """Run the 1x1 head of every branch on ``x`` through a chain of forks; -> (branch outputs, x for the
-    last consumer).  The last consumer (a pooling op or a strided conv) produces a fresh gradient tensor,
-    which each fork then accumulates into in place on the way back."""
-    outs = []
-    for b in branches:
-        y, x = _head(b).forward_fork(x)
-        outs.append(_tail(b, y))
-    return outs, x
-
-
-def _cat(xs):
-    # NHWC concat along channels keeps channels_last
-    return torch.cat(xs, 1)
+def _pre(m, x):
+    return m.conv(x), m.bn
 
 
 class InceptionA(nn.Module):          # Mixed_5b/5c/5d
@@ -76,8 +74,10 @@ class InceptionA(nn.Module):          # Mixed_5b/5c/5d
         self.b3 = ConvBN(i, pool, 1)
 
     def forward(self, x):
-        ys, x = _fan_out(x, [self.b0, self.b1, self.b2])
-        return _cat(ys + [self.b3(avg_pool2d(x, 3, 1, 1))])
+        p0, x = _branch(self.b0, x)
+        p1, x = _branch(self.b1, x)
+        p2, x = _branch(self.b2, x)
+        return bn_act_concat([p0, p1, p2, _pre(self.b3, avg_pool2d(x, 3, 1, 1))])
 
 
 class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
@@ -87,8 +87,8 @@ class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
         self.b1 = nn.Sequential(ConvBN(i, 64, 1), ConvBN(64, 96, 3, padding=1), ConvBN(96, 96, 3, stride=2))
 
     def forward(self, x):
-        (y1,), x = _fan_out(x, [self.b1])
-        return _cat([self.b0(x), y1, max_pool2d(x, 3, 2)])
+        p1, x = _branch(self.b1, x)
+        return bn_act_concat([_pre(self.b0, x), p1], extra=[max_pool2d(x, 3, 2)])
 
 
 class InceptionC(nn.Module):          # Mixed_6b..6e
@@ -103,8 +103,10 @@ class InceptionC(nn.Module):          # Mixed_6b..6e
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
-        ys, x = _fan_out(x, [self.b0, self.b1, self.b2])
-        return _cat(ys + [self.b3(avg_pool2d(x, 3, 1, 1))])
+        p0, x = _branch(self.b0, x)
+        p1, x = _branch(self.b1, x)
+        p2, x = _branch(self.b2, x)
+        return bn_act_concat([p0, p1, p2, _pre(self.b3, avg_pool2d(x, 3, 1, 1))])
 
 
 class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
@@ -115,8 +117,9 @@ class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
                                 ConvBN(192, 192, (7, 1), padding=(3, 0)), ConvBN(192, 192, 3, stride=2))
 
     def forward(self, x):
-        ys, x = _fan_out(x, [self.b0, self.b1])
-        return _cat(ys + [max_pool2d(x, 3, 2)])
+        p0, x = _branch(self.b0, x)
+        p1, x = _branch(self.b1, x)
+        return bn_act_concat([p0, p1], extra=[max_pool2d(x, 3, 2)])
 
 
 class InceptionE(nn.Module):          # Mixed_7b/7c
@@ -132,9 +135,12 @@ class InceptionE(nn.Module):          # Mixed_7b/7c
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
-        (y0, y1, y2), x = _fan_out(x, [self.b0, self.b1, self.b2])
-        return _cat([y0, self.b1a(y1), self.b1b(y1), self.b2a(y2), self.b2b(y2),
-                     self.b3(avg_pool2d(x, 3, 1, 1))])
+        p0, x = _branch(self.b0, x)
+        y1, x = self.b1.forward_fork(x)
+        h2, x = self.b2[0].forward_fork(x)
+        y2 = self.b2[1](h2)
+        return bn_act_concat([p0, _pre(self.b1a, y1), _pre(self.b1b, y1), _pre(self.b2a, y2), _pre(self.b2b, y2),
+                              _pre(self.b3, avg_pool2d(x, 3, 1, 1))])
 
 
 class AuxHead(nn.Module):

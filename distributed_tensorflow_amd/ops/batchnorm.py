@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from . import hip
 
 _declared = False
+_CONCAT = __import__("os").environ.get("DTF_BN_CONCAT", "1") != "0"      # A/B switch for bn_act_concat
 
 
 def _lib():
@@ -27,9 +28,9 @@ def _lib():
         P, I, L, Fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
         hip.declare("dtf_bn_partial_floats", [L, I], L)
         hip.declare("dtf_bn_mask_bytes", [L, I], L)
-        hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, P])
+        hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, L, P])
         hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, P, L, I, I, P])
-        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, P])
+        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, P])
         _declared = True
     return lib
 
@@ -82,7 +83,7 @@ class _FusedBNAct(torch.autograd.Function):
             hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
             hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
             stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-            hip.ptr(_partial(dev, M, C)), M, C, int(relu), hip.stream())
+            hip.ptr(_partial(dev, M, C)), M, C, int(relu), 0, hip.stream())
         hip.check(rc, "dtf_bn_fwd_train")
         ctx.save_for_backward(x, mask, weight, stats)
         # ReLU mask source for backward: 1 = recompute from x (no residual), 3 = bit mask
@@ -106,9 +107,95 @@ class _FusedBNAct(torch.autograd.Function):
             hip.ptr(dy), hip.ptr(x), hip.ptr(mask), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
             stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), hip.ptr(dres),
             dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
-            int(ctx.relu_mode), hip.stream())
+            int(ctx.relu_mode), 0, hip.stream())
         hip.check(rc, "dtf_bn_bwd_train")
         return dx, dgb[0], dgb[1], dres, None, None, None, None, None
+
+
+class _BNConcat(torch.autograd.Function):
+    """``cat([relu(bn_i(x_i)) ...] + passthrough, dim=1)`` for NHWC tensors in one autograd node: every
+    branch's K7 apply pass writes straight into its channel slice of the concat buffer (row stride =
+    total channels) and the backward kernels read their slice of the concat gradient in place -- no
+    concat copy forward, no slice copies backward (1.0 ms of a 23.5 ms Inception-v3 step).
+    args: nb, relu, then per branch (x, weight, bias, running_mean, running_var, momentum, eps), then the
+    pass-through tensors (e.g. a pooling branch), which are copied into / out of their slices."""
+
+    @staticmethod
+    def forward(ctx, nb, relu, *args):
+        lib = _lib()
+        branches = [args[7 * i:7 * i + 7] for i in range(nb)]
+        extra = list(args[7 * nb:])
+        x0 = branches[0][0]
+        N, _, H, W = x0.shape
+        dev = x0.device
+        chans = [b[0].shape[1] for b in branches] + [e.shape[1] for e in extra]
+        Ct = sum(chans)
+        out = torch.empty((N, Ct, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last)
+        M = N * H * W
+        saved, off = [], 0
+        for x, weight, bias, rm, rv, momentum, eps in branches:
+            C = x.shape[1]
+            stats = torch.empty(4, C, dtype=torch.float32, device=dev)
+            rc = lib.dtf_bn_fwd_train(
+                hip.ptr(x), None, out.data_ptr() + off * 2, None, hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
+                hip.ptr(rm), hip.ptr(rv), float(momentum), float(eps),
+                stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                hip.ptr(_partial(dev, M, C)), M, C, int(relu), Ct, hip.stream())
+            hip.check(rc, "dtf_bn_fwd_train (concat)")
+            saved += [x, weight, stats]
+            off += C
+        for e in extra:
+            out.narrow(1, off, e.shape[1]).copy_(e)
+            off += e.shape[1]
+        ctx.save_for_backward(*saved)
+        ctx.nb, ctx.relu, ctx.chans, ctx.M = nb, relu, chans, M
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib()
+        nb, chans, M = ctx.nb, ctx.chans, ctx.M
+        if not dout.is_contiguous(memory_format=torch.channels_last):
+            dout = dout.contiguous(memory_format=torch.channels_last)
+        Ct = dout.shape[1]
+        dev = dout.device
+        grads, off = [], 0
+        for i in range(nb):
+            x, weight, stats = ctx.saved_tensors[3 * i:3 * i + 3]
+            C = chans[i]
+            dx = torch.empty_like(x)
+            dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
+            coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+            rc = lib.dtf_bn_bwd_train(
+                dout.data_ptr() + off * 2, hip.ptr(x), None, hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
+                stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), None,
+                dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
+                1 if ctx.relu else 0, Ct, hip.stream())
+            hip.check(rc, "dtf_bn_bwd_train (concat)")
+            grads += [dx, dgb[0], dgb[1], None, None, None, None]
+            off += C
+        for C in chans[nb:]:
+            grads.append(dout.narrow(1, off, C).contiguous(memory_format=torch.channels_last))
+            off += C
+        return (None, None) + tuple(grads)
+
+
+def bn_act_concat(pairs, extra=(), relu=True):
+    """``torch.cat([bn(x) for x, bn in pairs] + list(extra), 1)`` with ``bn`` a :class:`FusedBatchNormAct`
+    (ReLU fused when ``relu``).  K7 + in-place slices for NHWC bf16 training tensors, plain composition
+    otherwise."""
+    xs = [x for x, _ in pairs]
+    ok = _CONCAT and all(kernel_eligible(x, m.weight) and m.training and m.relu == relu and x.dim() == 4 for x, m in pairs) \
+        and all(e.is_cuda and e.dtype == xs[0].dtype and e.dim() == 4 and e.shape[1] % 8 == 0 for e in extra) \
+        and torch.is_grad_enabled()
+    if not ok:
+        return torch.cat([m(x) for x, m in pairs] + list(extra), 1)
+    args = []
+    for x, m in pairs:
+        args += [x, m.weight, m.bias, m.running_mean, m.running_var, m.momentum, m.eps]
+    extra = [e if e.is_contiguous(memory_format=torch.channels_last) else e.contiguous(memory_format=torch.channels_last)
+             for e in extra]
+    return _BNConcat.apply(len(pairs), relu, *args, *extra)
 
 
 def bn_act_reference(x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):

@@ -701,3 +701,40 @@ def test_gemm_tn_matches_reference(dev, M, N, K):
     c2, cs = lin.gemm_tn(a, b, out_dtype=torch.float32, colsum_dtype=torch.float32)
     assert torch.equal(c2, c)
     torch.testing.assert_close(cs, a.float().sum(0), rtol=1e-3, atol=1e-2 * M ** 0.5 / 8)
+
+
+@pytest.mark.parametrize("with_extra", [False, True])
+def test_bn_act_concat_matches_cat_of_bn(dev, with_extra, monkeypatch):
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod
+
+    torch.manual_seed(0)
+    chans = [64, 96, 32]
+    N, H, W = 4, 9, 11
+    mods = [bnmod.FusedBatchNormAct(c, relu=True, eps=1e-3).to(dev).to(torch.bfloat16).train() for c in chans]
+    for m in mods:
+        with torch.no_grad():
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.uniform_(-0.5, 0.5)
+    xs = [torch.randn(N, c, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for c in chans]
+    extra = [torch.randn(N, 40, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)] if with_extra else []
+    dy = torch.randn(N, sum(chans) + (40 if with_extra else 0), H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(bnmod, "_CONCAT", fused)
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+            m.running_mean.zero_()
+            m.running_var.fill_(1.0)
+        x1 = [x.clone().requires_grad_() for x in xs]
+        e1 = [e.clone().requires_grad_() for e in extra]
+        y = bnmod.bn_act_concat(list(zip(x1, mods)), extra=e1)
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        res.append((y.detach().clone(), [x.grad.clone() for x in x1], [e.grad.clone() for e in e1],
+                    [m.weight.grad.clone() for m in mods], [m.bias.grad.clone() for m in mods],
+                    [m.running_var.clone() for m in mods]))
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    for i in range(1, 6):
+        for t1, t2 in zip(a[i], b[i]):
+            assert torch.equal(t1, t2)
