@@ -83,7 +83,7 @@ def main():
     if getattr(mod, "NEEDS_COMM", False):
         kw.update(comm=comm, device=dev)
     if not a.batch:
-        a.batch = {"inception_v3": 256, "inception3": 256, "bert": 64, "bert_base": 64, "wide_deep": 16384,
+        a.batch = {"inception_v3": 256, "inception3": 256, "bert": 64, "bert_base": 64, "wide_deep": 65536,
                    "mnist_mlp": 256, "mnist": 256}.get(key, 256)
     unit = {"bert": "sequences/sec", "bert_base": "sequences/sec", "wide_deep": "examples/sec"}.get(key, "images/sec")
     model = mod.build(**kw)
