@@ -25,7 +25,11 @@ def setup(force=False):
         return os.environ.get("MIOPEN_USER_DB_PATH")
     if not os.path.isdir(_SRC) or not os.listdir(_SRC):
         return None
-    base = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "dtf_miopen_%d" % os.getuid())
+    # one private copy per local rank: eight processes of one node otherwise share (and lock) one sqlite
+    # kernel cache and one find-db file while they all start at once
+    rank = os.environ.get("DTF_JOB_NAME", "") + os.environ.get(
+        "DTF_TASK_INDEX", os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0")))
+    base = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "dtf_miopen_%d_r%s" % (os.getuid(), rank))
     db, cache = os.path.join(base, "db"), os.path.join(base, "cache")
     try:
         os.makedirs(db, exist_ok=True)
