@@ -219,46 +219,81 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// 256 x 256 tile variant for large problems (>= ~2 tiles per CU): 8 waves as 2(M) x 4(N), each a
-// 128 x 64 sub-tile (8 x 4 accumulators = 128 fp32 regs), BK = 64, ~1 block per CU.
-// Staging is LDS-DMA (global_load_lds, 16 B per lane): no staging registers, no ds_write pass.  A
-// wave instruction fills 1 KB linearly (see the staging comment in the kernel).  Four 32 KB LDS buffers:
-// three K tiles stream in while one feeds the MFMAs; one raw barrier per K step.  Rows past M / N are clamped to the last valid row (their results are never
-// stored); K must be a multiple of 32 here (no zero fill with LDS-DMA) -- other K use the 128 kernel.
-// The fused epilogue runs in two 128-column halves through an fp32 LDS tile.
+// 256 x 256 tile variant for large problems: persistent blocks (one per CU) that walk the tile list,
+// 8 waves as 2(M) x 4(N), each a 128 x 64 sub-tile (8 x 4 accumulators = 128 fp32 regs), ~1 block/CU.
+//  * Staging is LDS-DMA (global_load_lds, 16 B per lane): no staging registers, no ds_write pass.
+//    K tiles of 32, FOUR 32 KB buffers.  One wave instruction fills 1 KB = the image of one 16-row MFMA
+//    fragment group ([16 rows][64 B], chunk-XOR-swizzled on the source side: conflict-free ds_read_b128).
+//  * Pipeline: three K tiles in flight while one feeds the MFMAs (one tile ahead is shorter than the
+//    loaded HBM/L2 latency: 50 % MFMA rate).  The LDS-DMA stays in flight ACROSS barriers: counted
+//    vmcnt (4 glds per wave per tile) and raw s_barrier -- __syncthreads() would drain vmcnt(0).
+//  * Ping-pong: the two waves that share a SIMD (w and w+4, wr = 0 / 1) run one barrier apart, so while
+//    one half of the block issues its 32 MFMAs the other half reads its fragments from LDS:
+//        wr=0:  R0 | M0 w1 | R1 | M1 w2 | ...     R = 12 ds_read_b128 (+ restage), M = 32 MFMAs,
+//        wr=1:     | R0 w1 | M0 | R1 w2 | ...     wN = wait for own pieces of tile N, | = s_barrier
+//    Tile N is first read (by wr=0) after the barrier that follows both groups' wN; buffers are restaged
+//    in phase R(t), which for both groups starts after the barrier that ended the last read of tile t-1.
+//  * K > 4096 stages tiles in PAIRS so the two 64-B halves of every 128-B line are requested back to back
+//    (8192^3: 931 -> 1155 TF); smaller K keeps the deeper one-tile-per-step schedule.
+//  * Epilogue straight from the accumulators: the MFMA operands are swapped (D = W.X^T fragment), so a
+//    lane holds 4 CONSECUTIVE output columns of one row -- bias / activation / residual in registers and
+//    8-byte stores (the four j fragments of a wave complete each 128-B line), no LDS round trip and no
+//    barriers.  LDS is therefore free during the epilogue: the first K tiles of the block's NEXT output
+//    tile are already streaming in while the current one is written out (with one block per CU nothing
+//    else would hide the prologue / epilogue: they were 60 % of a K = 768 tile's time).
+// Rows past M / N are clamped to the last valid row (their results are never stored); K must be a
+// multiple of 32 here (no zero fill with LDS-DMA) -- other K use the 128 kernel.
 // ---------------------------------------------------------------------------
 #define G2_BM 256
 #define G2_BN 256
-#define G2_LDC 132
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-__global__ __launch_bounds__(512) void gemm256_bias_act_kernel(GemmArgs a) {
+__device__ __forceinline__ float k6_act(float x, int act) {
+    if (act == ACT_RELU) return fmaxf(x, 0.f);
+    if (act == ACT_GELU) return gelu_tanh_free(x);
+    if (act == ACT_GELU_TANH) return gelu_tanh_fwd(x);
+    return x;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
-    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
     const int K = a.K;
+    const int nk = K / 32;
+    const bool pair = K > 4096;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int lane_off = frow * 64 + ((fq ^ ((4 - (frow >> 2)) & 3)) << 4);
 
-    // staging: K tiles of 32 (64-B LDS rows), FOUR 32 KB buffers.  One wave instruction fills 1 KB =
-    // 16 rows x 64 B, which is exactly the image of one 16-row MFMA fragment group: lane (frow, fq)
-    // reads byte frow*64 + fq*16 of it, i.e. the 64 lanes of a ds_read_b128 cover the 1 KB linearly --
-    // conflict-free with no swizzle.  Wave w stages row groups 2w, 2w+1 of A and of B.
     const unsigned short* pa[2];
     const unsigned short* pb[2];
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int tile) {        // wave w stages row groups 2w, 2w+1 of A and of B
+        const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
+        m0 = tm * G2_BM;
+        n0 = tn * G2_BN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 16 + (lane >> 2);
-        int gm = m0 + row, gn = n0 + row;
-        if (gm > a.M - 1) gm = a.M - 1;
-        if (gn > a.N - 1) gn = a.N - 1;
-        pa[i] = a.X + (int64_t)gm * K + (lane & 3) * 8;
-        pb[i] = a.W + (int64_t)gn * K + (lane & 3) * 8;
-    }
+        for (int i = 0; i < 2; ++i) {
+            // LDS-DMA lane l lands at byte 16 l of the 1 KB piece = [16 rows][4 chunks of 16 B] with 4
+            // consecutive lanes on one 64-B row segment (what the texture addresser coalesces; one lane per
+            // row measured 12-20 % slower).  Read plainly (frow*64 + fq*16) that image is 2-way conflicted:
+            // ds_read_b128 serves lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... and within a group
+            // the lanes of one fq all hit the same chunk column (PMC: 4 conflict cycles per read).  XOR the
+            // chunk with s(row >> 2), s = [0,3,2,1]: every group then covers all 16 chunk slots once.  The
+            // swizzle goes on the per-lane SOURCE address and on the read address.
+            const int row = (wave * 2 + i) * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);        // (row >> 2) & 3 == (lane >> 4) & 3
+            int gm = m0 + row, gn = n0 + row;
+            if (gm > a.M - 1) gm = a.M - 1;
+            if (gn > a.N - 1) gn = a.N - 1;
+            pa[i] = a.X + (int64_t)gm * K + chunk * 8;
+            pb[i] = a.W + (int64_t)gn * K + chunk * 8;
+        }
+    };
     auto stage = [&](int t) {
         unsigned char* base = smem + (t & 3) * 32768 + wave * 2048;
         const int k0 = t * 32;
@@ -268,160 +303,189 @@ __global__ __launch_bounds__(512) void gemm256_bias_act_kernel(GemmArgs a) {
             __builtin_amdgcn_global_load_lds((glb_void_t*)(pb[i] + k0), (lds_void_t*)(base + 16384 + i * 1024), 16, 0, 0);
         }
     };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // Pipeline.  (1) Tiles t+1 .. t+3 are in flight while tile t feeds the MFMAs (~3 K tiles of
-    // look-ahead; one tile ahead is shorter than the loaded HBM/L2 latency and ran at 50 % MFMA rate).
-    // The LDS-DMA stays in flight ACROSS barriers: counted vmcnt (4 glds per wave per tile) and raw
-    // s_barrier -- __syncthreads() would drain vmcnt(0).
-    // (2) Ping-pong: the two waves that share a SIMD (w and w+4, i.e. wr = 0 / 1) run one barrier apart,
-    // so while one half of the block issues its 32 MFMAs the other half reads its fragments from LDS:
-    //
-    //   wr=0:  R0 | M0 w1 | R1 | M1 w2 | R2 ...            R = 12 ds_read_b128 (+ restage), M = 32 MFMAs,
-    //   wr=1:     | R0 w1 | M0 | R1 w2 | M1 ...            wN = wait for own pieces of tile N, | = s_barrier
-    //
-    // Tile N is first read (by wr=0) after the barrier that follows both groups' wN.  Buffers (t+2)&3 and
-    // (t+3)&3 == (t-1)&3 are restaged in phase R(t), which for both groups starts after the barrier that
-    // ended the last read of tile t-1 (wr=1's R(t-1)).
-    const int nk = K / 32;
-    const int frow = lane & 15, fq = lane >> 4;
-    const int lane_off = frow * 64 + fq * 16;
-    // Tiles are staged in PAIRS (at even t: tiles t+2 and t+3) so that the two 64-B halves of every
-    // 128-B line of X / W are requested back to back -- one K tile at a time re-fetched half lines from
-    // HBM once the operand panels outgrew L2 (8192^3: 931 vs 1205 TF).
-    // tiles that may still be in flight when tile t+1 is needed: staged so far minus (t+1)
-    // K <= 4096 keeps the deeper single-tile schedule (stage t+3 every step): 4-8 % faster there.
-    const bool pair = K > 4096;
-#define G2_WAIT_NEXT(T)                                                              \
+    auto prologue = [&]() {
+        stage(0);
+        if (nk > 1) stage(1);
+        if (!pair && nk > 2) stage(2);
+    };
+    // tiles that may still be in flight when tile t+1 is needed: staged so far (UPTO) minus (t+1)
+#define G2_WAIT_NEXT(T, UPTO)                                                        \
     do {                                                                             \
-        int upto = (pair && ((T) & 1)) ? (T) + 2 : (T) + 3;                          \
+        int upto = (UPTO);                                                           \
         if (upto > nk - 1) upto = nk - 1;                                            \
         const int n_out = upto - ((T) + 1);                                          \
         if (n_out >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             \
         else if (n_out == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
     } while (0)
-    stage(0);
-    if (nk > 1) stage(1);
-    if (!pair && nk > 2) stage(2);
-    {
-        int staged = pair ? 2 : 3;
-        if (staged > nk) staged = nk;
-        if (staged == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (staged == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    int tile = xcd_remap(blockIdx.x, gridDim.x);        // neighbouring tiles on one XCD (shared L2)
+    if (tile < ntiles) {
+        set_tile(tile);
+        prologue();
     }
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave of every SIMD
-    for (int t = 0; t < nk; ++t) {
-        if (!pair) {
-            if (t + 3 < nk) stage(t + 3);
-        } else if ((t & 1) == 0) {
-            if (t + 2 < nk) stage(t + 2);
-            if (t + 3 < nk) stage(t + 3);
-        }
-        const unsigned char* A = smem + (t & 3) * 32768 + wr * 8192 + lane_off;
-        const unsigned char* B = smem + (t & 3) * 32768 + 16384 + wc * 4096 + lane_off;
-        bf16x8_t fa[8], fb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 1024);
-        if (wr == 1) G2_WAIT_NEXT(t);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int cm0 = m0, cn0 = n0;
+        f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (wr == 0) G2_WAIT_NEXT(t);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // the prefetched K tiles (and the previous epilogue's stores) have landed.  This wait must be the
+        // BUILTIN (a real S_WAITCNT the compiler's wait-count pass sees, vmcnt(0) = 0x0F70 on gfx9): with an
+        // asm string it still believes the epilogue's stores are pending at the K loop and drains
+        // vmcnt(0) before every LDS-DMA and every ds_read of the loop (measured: 1265 -> 800 TF).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef G2_WAIT_NEXT
-    __syncthreads();
-
-    float* ct = reinterpret_cast<float*>(smem);
-    const bool nvec = (a.N & 7) == 0;
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-        if ((wc >> 1) == h) {
+        if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave of every SIMD
+        for (int t = 0; t < nk; ++t) {
+            const unsigned char* A = smem + (t & 3) * 32768 + wr * 8192 + lane_off;
+            const unsigned char* B = smem + (t & 3) * 32768 + 16384 + wc * 4096 + lane_off;
+            bf16x8_t fa[8], fb[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 1024);
+            // wr=1 waits for tile t+1 here, BEFORE it restages in its M phase: staged so far = through t+2
+            // (pair mode: through t+1 at even t, t+2 at odd t)
+            if (wr == 1) G2_WAIT_NEXT(t, pair ? ((t & 1) ? t + 2 : t + 1) : t + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)      // operands swapped: D[n][m], 4 consecutive n per lane
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[0], acc[0][j], 0, 0, 0);
+            // the restage rides in the MFMA phase: an LDS-DMA piece costs 60-180 issue cycles, which made the
+            // READ phase (12 ds_read_b128 + 4 pieces) twice as long as the 512-cycle MFMA phase it overlaps
+            if (!pair) {
+                if (t + 3 < nk) stage(t + 3);
+            } else if ((t & 1) == 0) {
+                if (t + 2 < nk) stage(t + 2);
+                if (t + 3 < nk) stage(t + 3);
+            }
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (wr == 0) G2_WAIT_NEXT(t, (pair && (t & 1)) ? t + 2 : t + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two groups: every LDS read is done
+        __builtin_amdgcn_sched_barrier(0);
+        // bias of this tile first: an ordinary load's first use drains every LDS-DMA issued before it
+        float bv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = cn0 + wc * 64 + j * 16 + fq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
+            if ((a.N & 7) == 0 && a.bias && n < a.N) {
+                if (a.bias_dtype == DTF_BF16) {
+                    const u32x2 t2 = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(a.bias) + n);
+                    bv[j][0] = __uint_as_float(t2[0] << 16); bv[j][1] = __uint_as_float(t2[0] & 0xffff0000u);
+                    bv[j][2] = __uint_as_float(t2[1] << 16); bv[j][3] = __uint_as_float(t2[1] & 0xffff0000u);
+                } else {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.bias) + n);
+                    bv[j][0] = t4[0]; bv[j][1] = t4[1]; bv[j][2] = t4[2]; bv[j][3] = t4[3];
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + (int)gridDim.x < ntiles) {               // next tile's first K tiles stream in under the epilogue
+            set_tile(tile + gridDim.x);
+            prologue();
+        }
+
+        // ---- epilogue.  Lane (frow, fq) of fragment (i, j) holds row m = frow, columns 16j + 4fq .. +3:
+        // bias + activation in registers, then each wave transposes its 16 x 64 fragment row through a
+        // PRIVATE 4 KB piece of K-tile buffer 3 (free until the next tile's first restage; wave-private, so
+        // no block barrier: LDS operations of one wave complete in order) and writes full 128-B lines:
+        // 4 lanes x 32 B per row, residual added in fp32 before the single rounding.  The LDS accesses are
+        // inline asm so that the compiler does not drain the in-flight LDS-DMA of the next tile first.
+        if ((a.N & 7) == 0) {
+            const unsigned ebase = (unsigned)(uintptr_t)(lds_void_t*)smem + 98304u + (unsigned)wave * 4096u;
+            const int rrow = lane >> 2, rq = lane & 3;          // read-back: row, 16-column group
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = cm0 + wr * 128 + i * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = cn0 + wc * 64 + j * 16 + fq * 4;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                    if (a.preact && m < a.M && n < a.N) {
+                        u32x2 pk;
+                        pk[0] = pack_bf16x2(v[0], v[1]);
+                        pk[1] = pack_bf16x2(v[2], v[3]);
+                        *reinterpret_cast<u32x2*>(a.preact + (int64_t)m * a.N + n) = pk;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = k6_act(v[r], ACT);
+                    const unsigned wa = ebase + (unsigned)(frow * 256 + (((j * 4 + fq) ^ frow) << 4));
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(wa), "v"(v) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                f32x4 o4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned ra = ebase + (unsigned)(rrow * 256 + (((rq * 4 + q) ^ rrow) << 4));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(o4[q]) : "v"(ra) : "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const int om = cm0 + wr * 128 + i * 16 + rrow;
+                const int on = cn0 + wc * 64 + rq * 16;
+                if (om < a.M && on < a.N) {
+                    const int64_t o = (int64_t)om * a.N + on;
+                    float lo[8], hi[8];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { lo[k] = o4[0][k]; lo[4 + k] = o4[1][k]; hi[k] = o4[2][k]; hi[4 + k] = o4[3][k]; }
+                    const bool two = on + 8 < a.N;          // N % 8 == 0: the second octet is all-or-nothing
+                    if (a.residual) {
+                        float r8[8];
+                        load8<DTF_BF16>(a.residual, o, r8);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) lo[k] += r8[k];
+                        if (two) {
+                            load8<DTF_BF16>(a.residual, o + 8, r8);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) hi[k] += r8[k];
+                        }
+                    }
+                    store8<DTF_BF16>(a.Y, o, lo);
+                    if (two) store8<DTF_BF16>(a.Y, o + 8, hi);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = cm0 + wr * 128 + i * 16 + frow;
+                if (m >= a.M) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = wr * 128 + i * 16 + fq * 4 + r;
-                        const int col = (wc & 1) * 64 + j * 16 + frow;
-                        ct[row * G2_LDC + col] = acc[i][j][r];
+                        const int n = cn0 + wc * 64 + j * 16 + fq * 4 + r;
+                        if (n >= a.N) continue;
+                        const int64_t o = (int64_t)m * a.N + n;
+                        float x = acc[i][j][r];
+                        if (a.bias) x += (a.bias_dtype == DTF_BF16) ? load1<DTF_BF16>(a.bias, n) : load1<DTF_F32>(a.bias, n);
+                        if (a.preact) a.preact[o] = f32_to_bf16(x);
+                        x = k6_act(x, ACT);
+                        if (a.residual) x += bf16_to_f32(a.residual[o]);
+                        a.Y[o] = f32_to_bf16(x);
                     }
-        }
-        __syncthreads();
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-            const int item = tid + 512 * it;
-            const int row = item >> 4, c8 = (item & 15) << 3;
-            const int gm = m0 + row, gn = n0 + h * 128 + c8;
-            if (gm >= a.M || gn >= a.N) continue;
-            float v[8];
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + row * G2_LDC + c8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + row * G2_LDC + c8 + 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v[k] = lo[k]; v[4 + k] = hi[k]; }
-            const int64_t o = (int64_t)gm * a.N + gn;
-            if (nvec) {
-                if (a.bias) {
-                    float b[8];
-                    if (a.bias_dtype == DTF_BF16) load8<DTF_BF16>(a.bias, gn, b); else load8<DTF_F32>(a.bias, gn, b);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += b[k];
-                }
-                if (a.preact) store8<DTF_BF16>(a.preact, o, v);
-                if (a.act == ACT_RELU) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-                } else if (a.act == ACT_GELU) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = gelu_tanh_free(v[k]);
-                } else if (a.act == ACT_GELU_TANH) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = gelu_tanh_fwd(v[k]);
-                }
-                if (a.residual) {
-                    float r[8];
-                    load8<DTF_BF16>(a.residual, o, r);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += r[k];
-                }
-                store8<DTF_BF16>(a.Y, o, v);
-            } else {
-                for (int k = 0; k < 8 && gn + k < a.N; ++k) {
-                    float x = v[k];
-                    if (a.bias) x += (a.bias_dtype == DTF_BF16) ? load1<DTF_BF16>(a.bias, gn + k) : load1<DTF_F32>(a.bias, gn + k);
-                    if (a.preact) a.preact[o + k] = f32_to_bf16(x);
-                    if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
-                    else if (a.act == ACT_GELU) x = gelu_tanh_free(x);
-                else if (a.act == ACT_GELU_TANH) x = gelu_tanh_fwd(x);
-                    else if (a.act == ACT_GELU_TANH) x = gelu_tanh_fwd(x);
-                    if (a.residual) x += bf16_to_f32(a.residual[o + k]);
-                    a.Y[o + k] = f32_to_bf16(x);
-                }
             }
         }
-        __syncthreads();
     }
+#undef G2_WAIT_NEXT
 }
 
 // Backward helper of the fused epilogue: dZ = dY * act'(Z) (bf16) and dbias[n] = sum_m dZ[m,n]
@@ -520,10 +584,17 @@ int dtf_gemm_bias_act(const void* X, const void* W, const void* bias, int bias_d
                (M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN};
     static bool attr_set = false;
     const int lds = GM_BM * (GM_BN + 4) * 4;     // 67584 B: epilogue tile (>= 64 KB staging)
-    const int lds256 = G2_BM * G2_LDC * 4;       // 135168 B: epilogue half tile (>= 128 KB staging)
+    const int lds256 = 131072;                   // four 32 KB K-tile buffers
+    static int num_cu = 0;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_bias_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipFuncSetAttribute((const void*)gemm256_bias_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_GELU_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0) num_cu = 256;
         const char* e = getenv("DTF_GEMM_TILE");
         if (e && force_tile == 0) force_tile = atoi(e);
         attr_set = true;
@@ -535,7 +606,12 @@ int dtf_gemm_bias_act(const void* X, const void* W, const void* bias, int bias_d
     if (big) {
         a.ntm = ntm2;
         a.ntn = ntn2;
-        hipLaunchKernelGGL(gemm256_bias_act_kernel, dim3(ntm2 * ntn2), dim3(512), lds256, stream, a);
+        const int ntiles = ntm2 * ntn2;
+        const int grid = ntiles < num_cu ? ntiles : num_cu;
+        if (act == ACT_RELU) hipLaunchKernelGGL(gemm256p_kernel<ACT_RELU>, dim3(grid), dim3(512), lds256, stream, a, ntiles);
+        else if (act == ACT_GELU) hipLaunchKernelGGL(gemm256p_kernel<ACT_GELU>, dim3(grid), dim3(512), lds256, stream, a, ntiles);
+        else if (act == ACT_GELU_TANH) hipLaunchKernelGGL(gemm256p_kernel<ACT_GELU_TANH>, dim3(grid), dim3(512), lds256, stream, a, ntiles);
+        else hipLaunchKernelGGL(gemm256p_kernel<ACT_NONE>, dim3(grid), dim3(512), lds256, stream, a, ntiles);
     } else {
         hipLaunchKernelGGL(gemm_bias_act_kernel, dim3(a.ntm * a.ntn), dim3(256), lds, stream, a);
     }
