@@ -4,7 +4,8 @@ with job cleanup; the ``tf_cnn_benchmarks --model=inception3`` row of BASELINE.m
 Same MI355X recipe as ResNet: NHWC bf16, MIOpen convolutions, and every
 ``conv -> BatchNorm -> ReLU`` unit (TF-slim's ``conv2d`` with ``batch_norm``) uses the K7
 fused BN+ReLU kernels.  ~23.8 M parameters without the auxiliary head (``aux_logits=True``
-adds the ~3.4 M-parameter side classifier used by the TF-slim training recipe).
+adds the ~3.4 M-parameter side classifier used by the TF-slim training recipe).  The 3x3/1 pooling
+branches average over real pixels only (TF's 'SAME' avg_pool; ``count_include_pad=False``).
 Variable names follow TF-slim's ``InceptionV3`` scope (``InceptionV3/Conv2d_1a_3x3/weights``,
 ``InceptionV3/Mixed_5b/Branch_1/Conv2d_0a_1x1/BatchNorm/beta``, ``InceptionV3/Logits/...``).
 """
@@ -77,7 +78,7 @@ class InceptionA(nn.Module):          # Mixed_5b/5c/5d
         p0, x = _branch(self.b0, x)
         p1, x = _branch(self.b1, x)
         p2, x = _branch(self.b2, x)
-        return bn_act_concat([p0, p1, p2, _pre(self.b3, avg_pool2d(x, 3, 1, 1))])
+        return bn_act_concat([p0, p1, p2, _pre(self.b3, avg_pool2d(x, 3, 1, 1, count_include_pad=False))])
 
 
 class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
@@ -106,7 +107,7 @@ class InceptionC(nn.Module):          # Mixed_6b..6e
         p0, x = _branch(self.b0, x)
         p1, x = _branch(self.b1, x)
         p2, x = _branch(self.b2, x)
-        return bn_act_concat([p0, p1, p2, _pre(self.b3, avg_pool2d(x, 3, 1, 1))])
+        return bn_act_concat([p0, p1, p2, _pre(self.b3, avg_pool2d(x, 3, 1, 1, count_include_pad=False))])
 
 
 class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
@@ -140,7 +141,7 @@ class InceptionE(nn.Module):          # Mixed_7b/7c
         h2, x = self.b2[0].forward_fork(x)
         y2 = self.b2[1](h2)
         return bn_act_concat([p0, _pre(self.b1a, y1), _pre(self.b1b, y1), _pre(self.b2a, y2), _pre(self.b2b, y2),
-                              _pre(self.b3, avg_pool2d(x, 3, 1, 1))])
+                              _pre(self.b3, avg_pool2d(x, 3, 1, 1, count_include_pad=False))])
 
 
 class AuxHead(nn.Module):
