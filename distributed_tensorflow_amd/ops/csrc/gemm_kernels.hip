@@ -46,7 +46,7 @@ __device__ __forceinline__ float fast_erf(float x) {
     return copysignf(e, x);
 }
 
-__device__ __forceinline__ float gelu_tanh_free(float x) {
+__device__ __forceinline__ float gelu_erf(float x) {
     // exact (erf) GELU like torch.nn.functional.gelu default
     return 0.5f * x * (1.f + fast_erf(x * 0.70710678118654752f));
 }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(GemmArgs a) {
                 for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
             } else if (a.act == ACT_GELU) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = gelu_tanh_free(v[k]);
+                for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
             } else if (a.act == ACT_GELU_TANH) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = gelu_tanh_fwd(v[k]);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(GemmArgs a) {
                 if (a.bias) x += (a.bias_dtype == DTF_BF16) ? load1<DTF_BF16>(a.bias, gn + k) : load1<DTF_F32>(a.bias, gn + k);
                 if (a.preact) a.preact[o + k] = f32_to_bf16(x);
                 if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
-                else if (a.act == ACT_GELU) x = gelu_tanh_free(x);
+                else if (a.act == ACT_GELU) x = gelu_erf(x);
                 else if (a.act == ACT_GELU_TANH) x = gelu_tanh_fwd(x);
                 if (a.residual) x += bf16_to_f32(a.residual[o + k]);
                 a.Y[o + k] = f32_to_bf16(x);
@@ -252,7 +252,7 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 __device__ __forceinline__ float k6_act(float x, int act) {
     if (act == ACT_RELU) return fmaxf(x, 0.f);
-    if (act == ACT_GELU) return gelu_tanh_free(x);
+    if (act == ACT_GELU) return gelu_erf(x);
     if (act == ACT_GELU_TANH) return gelu_tanh_fwd(x);
     return x;
 }
