@@ -3,8 +3,8 @@
 L=12, H=768, A=12, intermediate 3072, vocab 30522, masked-LM + next-sentence heads; ~110 M
 parameters whose Adam state (fp32 master + m + v) is sharded over the PS ranks and updated
 by the K2 fused Adam shard-apply kernel.  Linear layers are :class:`FusedLinear` (K6 MFMA
-GEMM with the bias / GELU / residual epilogue fused); attention uses PyTorch SDPA (not a
-north-star kernel).
+GEMM with the bias / GELU / residual epilogue fused, K6T weight gradients), LayerNorm is K10 and
+attention is K11 (``ops/attention.py``; PyTorch SDPA when a mask or dropout is requested).
 
 Variables are named like google-research/bert checkpoints: ``bert/embeddings/word_embeddings``,
 ``bert/encoder/layer_0/attention/self/query/kernel``, ``cls/predictions/transform/dense/kernel``
@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops import attention
 from ..ops.layernorm import FusedLayerNorm
 from ..ops.linear import FusedLinear
 
@@ -53,10 +54,16 @@ class Layer(nn.Module):
         B, S, H = x.shape
         # x feeds the projection and the residual: the fork sums both gradients inside the dX GEMM
         qkv, x = self.qkv.forward_fork(x, own_skip_grad=True)
-        q, k, v = _SplitQKV.apply(qkv.view(B, S, 3, self.A, H // self.A))
-        ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask,
-                                             dropout_p=self.p if self.training else 0.0)
-        ctx = ctx.transpose(1, 2).reshape(B, S, H)
+        qkv5 = qkv.view(B, S, 3, self.A, H // self.A)
+        drop = self.p if self.training else 0.0
+        if mask is None and drop == 0.0 and attention.kernel_eligible(qkv5):
+            # K11: consumes the packed projection in place, writes the context token-major, and its backward
+            # writes dQ / dK / dV straight into the packed gradient -- no transposes or copies either way
+            ctx = attention.attention_packed(qkv5)
+        else:
+            q, k, v = _SplitQKV.apply(qkv5)
+            ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=drop)
+            ctx = ctx.transpose(1, 2).reshape(B, S, H)
         x = self.attn_ln(self.attn_out(ctx, residual=x))          # residual fused in the GEMM epilogue
         h, x = self.inter.forward_fork(x, own_skip_grad=True)
         return self.out_ln(self.out(h, residual=x))

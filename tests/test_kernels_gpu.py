@@ -738,3 +738,45 @@ def test_bn_act_concat_matches_cat_of_bn(dev, with_extra, monkeypatch):
     for i in range(1, 6):
         for t1, t2 in zip(a[i], b[i]):
             assert torch.equal(t1, t2)
+
+
+@pytest.mark.parametrize("B,S,A", [(2, 512, 3), (1, 128, 2), (3, 384, 1), (1, 256, 4)])
+def test_attention_forward_matches_reference(dev, B, S, A):
+    from distributed_tensorflow_amd.ops import attention as att
+
+    torch.manual_seed(0)
+    qkv = (torch.randn(B, S, 3, A, 64, device=dev) * 1.5).to(torch.bfloat16)
+    assert att.kernel_eligible(qkv)
+    o, lse = att.attn_fwd_packed(qkv)
+    q, k, v = qkv.float().permute(2, 0, 3, 1, 4).unbind(0)
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, A * 64)
+    torch.testing.assert_close(o.float(), ref, rtol=2e-2, atol=2e-2)
+    ref_lse = torch.logsumexp(s, -1) * 1.4426950408889634
+    torch.testing.assert_close(lse, ref_lse, rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("B,S,A", [(2, 512, 3), (2, 128, 2), (1, 384, 1), (1, 256, 4)])
+def test_attention_backward_matches_reference(dev, B, S, A):
+    from distributed_tensorflow_amd.ops import attention as att
+
+    torch.manual_seed(0)
+    qkv = (torch.randn(B, S, 3, A, 64, device=dev) * 1.2).to(torch.bfloat16)
+    do = torch.randn(B, S, A * 64, device=dev).to(torch.bfloat16)
+    x1 = qkv.clone().requires_grad_()
+    o1 = att.attention_packed(x1)
+    o1.backward(do)
+    x2 = qkv.float().requires_grad_()
+    q, k, v = x2.permute(2, 0, 3, 1, 4).unbind(0)
+    o2 = (torch.softmax((q @ k.transpose(-1, -2)) / 8.0, -1) @ v).transpose(1, 2).reshape(B, S, A * 64)
+    o2.backward(do.float())
+    torch.testing.assert_close(o1.float(), o2, rtol=2e-2, atol=2e-2)
+    g1, g2 = x1.grad.float(), x2.grad
+    for i, name in enumerate("qkv"):
+        err = float((g1[:, :, i] - g2[:, :, i]).norm() / g2[:, :, i].norm())
+        assert err < 0.02, (name, err)
+    torch.testing.assert_close(g1, g2, rtol=5e-2, atol=3e-2)
+    # deterministic
+    x3 = qkv.clone().requires_grad_()
+    att.attention_packed(x3).backward(do)
+    assert torch.equal(x3.grad, x1.grad)
