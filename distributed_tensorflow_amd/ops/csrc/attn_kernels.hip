@@ -283,6 +283,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdArgs a) {
         const int64_t li = ((int64_t)b * a.A + h) * S + q;
         if (g == 0) a.Dsum[li] = dsum;
         const float l2 = a.LSE[li];
+        const float dss = dsum * a.scale;            // dS = P o (dP - D) * scale = P o fma(dP, scale, -D * scale)
 
         f32x4 dq[4];
 #pragma unroll
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(sc[u][r], c, -l2));
-                    sc[u][r] = p * (dp[u][r] - dsum) * a.scale;
+                    sc[u][r] = p * fmaf(dp[u][r], a.scale, -dss);
                 }
             const at_s16x8 dsf = at_pack8(sc[0], sc[1]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     at_stage_image<NKT, NT>(Gimg, a.dO + (int64_t)b * S * H + h * AT_D, H, tid);
     for (int i = tid; i < S; i += NT) {
         Ls[i] = a.LSE[((int64_t)b * a.A + h) * S + i];
-        Ds[i] = a.Dsum[((int64_t)b * a.A + h) * S + i];
+        Ds[i] = a.Dsum[((int64_t)b * a.A + h) * S + i] * a.scale;
     }
     __syncthreads();
 
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(sc[u][r], c, -l2[u][r]));
                     sc[u][r] = p;
-                    dp[u][r] = p * (dp[u][r] - dd[u][r]) * a.scale;
+                    dp[u][r] = p * fmaf(dp[u][r], a.scale, -dd[u][r]);
                 }
             const at_s16x8 pf = at_pack8(sc[0], sc[1]);
             const at_s16x8 dsf = at_pack8(dp[0], dp[1]);
@@ -501,19 +502,24 @@ int dtf_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
                   q_bs, k_bs, v_bs, dq_bs, dk_bs, dv_bs, q_rs, k_rs, v_rs, dq_rs, dk_rs, dv_rs, B, A, S,
                   scale * 1.4426950408889634f, scale};
     static bool attr_set = false;
+    static int dq_nt = 1024;
     const int lds1 = 2 * AT_MAXS * 128, lds2 = 2 * AT_MAXS * 128 + 2 * AT_MAXS * 4;
 #define AT_FOR_S(X) X(32) X(24) X(16) X(8)
     if (!attr_set) {
 #define AT_ATTR(N)                                                                                                   \
         hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<N, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1); \
+        hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<N, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1); \
         hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<N, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
         AT_FOR_S(AT_ATTR)
 #undef AT_ATTR
+        const char* e = getenv("DTF_ATTN_DQ_THREADS");
+        if (e && atoi(e) == 512) dq_nt = 512;
         attr_set = true;
     }
 #define AT_LAUNCH(N)                                                                                            \
     if (S == N * 16) {                                                                                          \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<N, 512>), dim3(B * A), dim3(512), lds1, stream, a);              \
+        if (dq_nt == 1024) hipLaunchKernelGGL((attn_bwd_dq_kernel<N, 1024>), dim3(B * A), dim3(1024), lds1, stream, a); \
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<N, 512>), dim3(B * A), dim3(512), lds1, stream, a);              \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<N, 512>), dim3(B * A), dim3(512), lds2, stream, a);             \
     }
     AT_FOR_S(AT_LAUNCH)
