@@ -40,6 +40,12 @@ __device__ __forceinline__ at_s16x4 at_tr_read(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// same, 16 rows (2048 B) further down the image
+__device__ __forceinline__ at_s16x4 at_tr_read_16(unsigned addr) {
+    at_s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(v) : "v"(addr));
+    return v;
+}
 
 // K image: [key][128 B], 16-B chunk c of row r at chunk c ^ ((r >> 1) & 7): conflict-free ds_read_b128 of
 // an A fragment (16 keys x 32 d).  V image: [key][128 B], 32-B chunk c of row r at c ^ ((r >> 1) & 3):
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs a) {
         for (int ks = 0; ks < 2; ++ks)
             qf[ks] = *reinterpret_cast<const at_s16x8*>(Qh + (int64_t)(q0 + fr) * a.q_rs + ks * 32 + g * 8);
 
-        float mx = -INFINITY;
+        float mx = -3.0e38f;
 #pragma unroll
         for (int tb = 0; tb < NKT; tb += 4) {
             at_s16x8 kf[4][2];
@@ -129,6 +135,11 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs a) {
         const float mc = mx * c;
 
         float sum = 0.f;
+        // transposed-read addresses: the image swizzle depends on (row >> 1) & 3 only, which neither the
+        // 32-row step nor the +16-row second read changes -> one running address per d tile
+        unsigned vb[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vb[dt] = vbase + at_v_off(4 * g + tq, dt * 2) + tp * 8;
         f32x4 oacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -140,12 +151,12 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
                     kf[u][ks] = *reinterpret_cast<const at_s16x8*>(Kimg + at_k_off((2 * s + u) * 16 + fr, ks * 4 + g));
-            const int r0 = 32 * s + 4 * g + tq;
             at_s16x4 lo[4], hi[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                lo[dt] = at_tr_read(vbase + at_v_off(r0, dt * 2) + tp * 8);
-                hi[dt] = at_tr_read(vbase + at_v_off(r0 + 16, dt * 2) + tp * 8);
+                lo[dt] = at_tr_read(vb[dt]);
+                hi[dt] = at_tr_read_16(vb[dt]);
+                vb[dt] += 4096;                       // 32 keys further
             }
             f32x4 sc[2];
 #pragma unroll
@@ -285,6 +296,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdArgs a) {
         const float l2 = a.LSE[li];
         const float dss = dsum * a.scale;            // dS = P o (dP - D) * scale = P o fma(dP, scale, -D * scale)
 
+        unsigned kb[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) kb[dt] = kbase + at_v_off(4 * g + tq, dt * 2) + tp * 8;
         f32x4 dq[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -299,12 +313,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdArgs a) {
                     kf[u][ks] = *reinterpret_cast<const at_s16x8*>(Kimg + off);
                     vf[u][ks] = *reinterpret_cast<const at_s16x8*>(Vimg + off);
                 }
-            const int r0 = 32 * s + 4 * g + tq;
             at_s16x4 lo[4], hi[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                lo[dt] = at_tr_read(kbase + at_v_off(r0, dt * 2) + tp * 8);
-                hi[dt] = at_tr_read(kbase + at_v_off(r0 + 16, dt * 2) + tp * 8);
+                lo[dt] = at_tr_read(kb[dt]);
+                hi[dt] = at_tr_read_16(kb[dt]);
+                kb[dt] += 4096;
             }
             f32x4 sc[2], dp[2];
 #pragma unroll
@@ -378,6 +392,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
             kf[ks] = *reinterpret_cast<const at_s16x8*>(krow + ks * 32 + g * 8);
             vf[ks] = *reinterpret_cast<const at_s16x8*>(vrow + ks * 32 + g * 8);
         }
+        unsigned tb[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) tb[dt] = qbase + at_v_off(4 * g + tq, dt * 2) + tp * 8;
+        const unsigned gdelta = gbase - qbase;
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -395,15 +413,14 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
                     qa[u][ks] = *reinterpret_cast<const at_s16x8*>(Qimg + off);
                     ga[u][ks] = *reinterpret_cast<const at_s16x8*>(Gimg + off);
                 }
-            const int r0 = 32 * s + 4 * g + tq;
             at_s16x4 qlo[4], qhi[4], glo[4], ghi[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const unsigned o0 = at_v_off(r0, dt * 2) + tp * 8, o1 = at_v_off(r0 + 16, dt * 2) + tp * 8;
-                qlo[dt] = at_tr_read(qbase + o0);
-                qhi[dt] = at_tr_read(qbase + o1);
-                glo[dt] = at_tr_read(gbase + o0);
-                ghi[dt] = at_tr_read(gbase + o1);
+                qlo[dt] = at_tr_read(tb[dt]);
+                qhi[dt] = at_tr_read_16(tb[dt]);
+                glo[dt] = at_tr_read(tb[dt] + gdelta);
+                ghi[dt] = at_tr_read_16(tb[dt] + gdelta);
+                tb[dt] += 4096;
             }
             f32x4 sc[2], dp[2], l2[2], dd[2];
 #pragma unroll
