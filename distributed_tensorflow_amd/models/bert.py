@@ -50,16 +50,17 @@ class Layer(nn.Module):
         self.out_ln = FusedLayerNorm(H, eps=1e-12)
         self.p = p
 
-    def forward(self, x, mask):
+    def forward(self, x, mask, kv_len=None):
         B, S, H = x.shape
         # x feeds the projection and the residual: the fork sums both gradients inside the dX GEMM
         qkv, x = self.qkv.forward_fork(x, own_skip_grad=True)
         qkv5 = qkv.view(B, S, 3, self.A, H // self.A)
         drop = self.p if self.training else 0.0
-        if mask is None and drop == 0.0 and attention.kernel_eligible(qkv5):
+        if drop == 0.0 and attention.kernel_eligible(qkv5):
             # K11: consumes the packed projection in place, writes the context token-major, and its backward
-            # writes dQ / dK / dV straight into the packed gradient -- no transposes or copies either way
-            ctx = attention.attention_packed(qkv5)
+            # writes dQ / dK / dV straight into the packed gradient -- no transposes or copies either way.
+            # The padding mask is a prefix mask: handed over as one length per sequence.
+            ctx = attention.attention_packed(qkv5, kv_len)
         else:
             q, k, v = _SplitQKV.apply(qkv5)
             ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=drop)
@@ -100,11 +101,13 @@ class Bert(nn.Module):
         x = self.word_embeddings(input_ids) + self.position_embeddings(pos).unsqueeze(0) \
             + self.token_type_embeddings(token_type_ids)
         x = self.emb_ln(x)
-        mask = None
+        mask = kv_len = None
         if attention_mask is not None:
+            # BERT's input mask marks real tokens with 1 and trailing padding with 0 (a prefix mask)
             mask = attention_mask[:, None, None, :].to(torch.bool)
+            kv_len = attention_mask.sum(-1, dtype=torch.int32)
         for layer in self.layers:
-            x = layer(x, mask)
+            x = layer(x, mask, kv_len)
         pooled = torch.tanh(self.pooler(x[:, 0]))
         # masked-LM head on the masked positions only (max_predictions_per_seq)
         idx = masked_positions.unsqueeze(-1).expand(-1, -1, self.hidden)

@@ -1,5 +1,5 @@
 // K11: self-attention for BERT-sized heads on gfx950 -- head_dim 64, sequence length 128 / 256 / 384 / 512,
-// no mask, no dropout (config #4).  One workgroup owns one (batch, head): K and V of the whole
+// optional key-padding mask (one valid length per sequence), no dropout (config #4).  One workgroup owns one (batch, head): K and V of the whole
 // sequence stay resident in LDS (2 x 64 KB at S = 512), so they are read from HBM/L2 exactly once per
 // head, and every wave computes COMPLETE score rows -- no online-softmax rescaling:
 //
@@ -33,6 +33,7 @@ struct AttnArgs {
     int q_rs, k_rs, v_rs;                 // row (token) strides (elements)
     int B, A, S;
     float scale_log2e;
+    const int* kv_len;                    // optional [B]: keys >= kv_len[b] are masked out (padding); null = none
 };
 
 __device__ __forceinline__ at_s16x4 at_tr_read(unsigned addr) {
@@ -53,7 +54,7 @@ __device__ __forceinline__ at_s16x4 at_tr_read_16(unsigned addr) {
 __device__ __forceinline__ int at_k_off(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int at_v_off(int row, int c16) { return row * 128 + ((((c16 >> 1) ^ ((row >> 1) & 3)) << 5) | ((c16 & 1) << 4)); }
 
-template <int NKT, int NT>      // key tiles of 16 = S / 16 (the score tile lives in 4 * NKT registers); threads
+template <int NKT, int NT, bool MASKED>      // key tiles of 16 = S / 16; threads; key-padding mask compiled in
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Kimg = smem;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs a) {
     //   pass 2: S^T tiles again (the extra 64 MFMAs are cheaper than holding the scores), p = exp2(.),
     //           row sum, bf16 P fragment, O^T += V^T . P^T.
     const float c = a.scale_log2e;
+    const int klen = MASKED ? a.kv_len[b] : S;      // block-uniform
     for (int qt = wave; qt < NKT; qt += NT / 64) {
         const int q0 = qt * 16;
         // Q fragments as the B operand: lane (q = fr, group g) holds d = 32 ks + 8 g .. + 7
@@ -127,6 +129,10 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs a) {
                 f32x4 sc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][ks], qf[ks], sc, 0, 0, 0);
+                if (MASKED && 16 * (tb + u + 1) > klen) {          // tile reaches into the padding (uniform branch)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[r] = (16 * (tb + u) + 4 * g + r < klen) ? sc[r] : -3.0e38f;
+                }
                 mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), mx);
             }
         }
@@ -166,12 +172,17 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(AttnArgs a) {
                 for (int ks = 0; ks < 2; ++ks) sc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[u][ks], qf[ks], sc[u], 0, 0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                if (MASKED && 16 * (2 * s + u + 1) > klen) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[u][r] = (16 * (2 * s + u) + 4 * g + r < klen) ? sc[u][r] : -3.0e38f;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     sc[u][r] = __builtin_amdgcn_exp2f(fmaf(sc[u][r], c, -mc));      // arguments <= 0
                     sum += sc[u][r];
                 }
+            }
             const u32x4 pk = {pack_bf16x2(sc[0][0], sc[0][1]), pack_bf16x2(sc[0][2], sc[0][3]),
                               pack_bf16x2(sc[1][0], sc[1][1]), pack_bf16x2(sc[1][2], sc[1][3])};
             const at_s16x8 pf = __builtin_bit_cast(at_s16x8, pk);
@@ -220,6 +231,7 @@ struct AttnBwdArgs {
     int q_rs, k_rs, v_rs, dq_rs, dk_rs, dv_rs;
     int B, A, S;
     float scale_log2e, scale;
+    const int* kv_len;
 };
 
 // dual-use image: [row][128 B], 32-B chunk c of row r at c ^ ((r >> 1) & 3); conflict-free for the
@@ -258,7 +270,7 @@ __device__ __forceinline__ float at_dot8(const at_s16x8& x, const at_s16x8& y) {
     return s;
 }
 
-template <int NKT, int NT>
+template <int NKT, int NT, bool MASKED>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Kimg = smem;
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     const int tq = (lane >> 2) & 3, tp = lane & 3;
     const unsigned kbase = (unsigned)(uintptr_t)(at_lds_void*)Kimg;
     const float c = a.scale_log2e;
+    const int klen = MASKED ? a.kv_len[b] : S;
     for (int qt = wave; qt < NKT; qt += NT / 64) {
         const int q = qt * 16 + fr;
         const unsigned short* qrow = a.Q + b * a.q_bs + h * AT_D + (int64_t)q * a.q_rs;
@@ -335,7 +348,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdArgs a) {
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[u][r], c, -l2));
+                    float p = __builtin_amdgcn_exp2f(fmaf(sc[u][r], c, -l2));
+                    if (MASKED && 16 * (2 * s + u + 1) > klen) p = (16 * (2 * s + u) + 4 * g + r < klen) ? p : 0.f;
                     sc[u][r] = p * fmaf(dp[u][r], a.scale, -dss);
                 }
             const at_s16x8 dsf = at_pack8(sc[0], sc[1]);
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_kernel(AttnBwdArgs a) {
     }
 }
 
-template <int NKT, int NT>
+template <int NKT, int NT, bool MASKED>
 __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Qimg = smem;
@@ -382,8 +396,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
     const unsigned qbase = (unsigned)(uintptr_t)(at_lds_void*)Qimg;
     const unsigned gbase = (unsigned)(uintptr_t)(at_lds_void*)Gimg;
     const float c = a.scale_log2e;
+    const int klen = MASKED ? a.kv_len[b] : S;
     for (int kt = wave; kt < NKT; kt += NT / 64) {
         const int key = kt * 16 + fr;
+        const bool kvalid = !MASKED || key < klen;           // padded keys take no probability mass: dK = dV = 0
         const unsigned short* krow = a.K + b * a.k_bs + h * AT_D + (int64_t)key * a.k_rs;
         const unsigned short* vrow = a.V + b * a.v_bs + h * AT_D + (int64_t)key * a.v_rs;
         at_s16x8 kf[2], vf[2];
@@ -439,7 +455,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[u][r], c, -l2[u][r]));
+                    float p = __builtin_amdgcn_exp2f(fmaf(sc[u][r], c, -l2[u][r]));
+                    if (MASKED) p = kvalid ? p : 0.f;
                     sc[u][r] = p;
                     dp[u][r] = p * fmaf(dp[u][r], a.scale, -dd[u][r]);
                 }
@@ -476,26 +493,32 @@ extern "C" {
 // o: bf16 [B, S, A*64]; lse: fp32 [B, A, S] (log2 domain, includes the scale).
 int dtf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int64_t q_bs, int64_t k_bs,
                  int64_t v_bs, int q_rs, int k_rs, int v_rs, int B, int A, int S, int D, float scale,
-                 hipStream_t stream) {
+                 const int* kv_len, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (D != AT_D || (S != 512 && S != 384 && S != 256 && S != 128) || B <= 0 || A <= 0) return -70;
     if ((q_rs | k_rs | v_rs) & 7) return -71;
     if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)o)) & 15) return -16;
     AttnArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (unsigned short*)o, lse,
-               q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, B, A, S, scale * 1.4426950408889634f};
+               q_bs, k_bs, v_bs, q_rs, k_rs, v_rs, B, A, S, scale * 1.4426950408889634f, kv_len};
     static bool attr_set = false;
     static int nt = 1024;
     const int lds = 2 * AT_MAXS * 128;
 #define AT_FOR_ALL(X) X(32, 512) X(24, 512) X(16, 512) X(8, 512) X(32, 1024) X(24, 1024) X(16, 1024) X(8, 1024)
     if (!attr_set) {
-#define AT_ATTR(N, T) hipFuncSetAttribute((const void*)attn_fwd_kernel<N, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#define AT_ATTR(N, T)                                                                                                  \
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<N, T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipFuncSetAttribute((const void*)attn_fwd_kernel<N, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         AT_FOR_ALL(AT_ATTR)
 #undef AT_ATTR
         const char* e = getenv("DTF_ATTN_THREADS");
         if (e && atoi(e) == 512) nt = 512;
         attr_set = true;
     }
-#define AT_LAUNCH(N, T) if (S == N * 16 && nt == T) hipLaunchKernelGGL((attn_fwd_kernel<N, T>), dim3(B * A), dim3(T), lds, stream, a);
+#define AT_LAUNCH(N, T)                                                                                        \
+    if (S == N * 16 && nt == T) {                                                                              \
+        if (kv_len) hipLaunchKernelGGL((attn_fwd_kernel<N, T, true>), dim3(B * A), dim3(T), lds, stream, a);   \
+        else hipLaunchKernelGGL((attn_fwd_kernel<N, T, false>), dim3(B * A), dim3(T), lds, stream, a);         \
+    }
     AT_FOR_ALL(AT_LAUNCH)
 #undef AT_LAUNCH
 #undef AT_FOR_ALL
@@ -508,7 +531,7 @@ int dtf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* ls
 int dtf_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* do_, const float* lse,
                  float* dsum, void* dq, void* dk, void* dv, int64_t q_bs, int64_t k_bs, int64_t v_bs, int q_rs, int k_rs,
                  int v_rs, int64_t dq_bs, int64_t dk_bs, int64_t dv_bs, int dq_rs, int dk_rs, int dv_rs, int B, int A,
-                 int S, int D, float scale, hipStream_t stream) {
+                 int S, int D, float scale, const int* kv_len, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (D != AT_D || (S != 512 && S != 384 && S != 256 && S != 128) || B <= 0 || A <= 0) return -70;
     if ((q_rs | k_rs | v_rs | dq_rs | dk_rs | dv_rs) & 7) return -71;
@@ -517,29 +540,35 @@ int dtf_attn_bwd(const void* q, const void* k, const void* v, const void* o, con
     AttnBwdArgs a{(const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v, (const unsigned short*)o,
                   (const unsigned short*)do_, lse, dsum, (unsigned short*)dq, (unsigned short*)dk, (unsigned short*)dv,
                   q_bs, k_bs, v_bs, dq_bs, dk_bs, dv_bs, q_rs, k_rs, v_rs, dq_rs, dk_rs, dv_rs, B, A, S,
-                  scale * 1.4426950408889634f, scale};
+                  scale * 1.4426950408889634f, scale, kv_len};
     static bool attr_set = false;
     static int dq_nt = 1024;
     const int lds1 = 2 * AT_MAXS * 128, lds2 = 2 * AT_MAXS * 128 + 2 * AT_MAXS * 4;
 #define AT_FOR_S(X) X(32) X(24) X(16) X(8)
     if (!attr_set) {
-#define AT_ATTR(N)                                                                                                   \
-        hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<N, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1); \
-        hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<N, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1); \
-        hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<N, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+#define AT_ATTR1(N, M)                                                                                                  \
+        hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<N, 512, M>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1);  \
+        hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<N, 1024, M>, hipFuncAttributeMaxDynamicSharedMemorySize, lds1); \
+        hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<N, 512, M>, hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+#define AT_ATTR(N) AT_ATTR1(N, false) AT_ATTR1(N, true)
         AT_FOR_S(AT_ATTR)
 #undef AT_ATTR
+#undef AT_ATTR1
         const char* e = getenv("DTF_ATTN_DQ_THREADS");
         if (e && atoi(e) == 512) dq_nt = 512;
         attr_set = true;
     }
-#define AT_LAUNCH(N)                                                                                            \
-    if (S == N * 16) {                                                                                          \
-        if (dq_nt == 1024) hipLaunchKernelGGL((attn_bwd_dq_kernel<N, 1024>), dim3(B * A), dim3(1024), lds1, stream, a); \
-        else hipLaunchKernelGGL((attn_bwd_dq_kernel<N, 512>), dim3(B * A), dim3(512), lds1, stream, a);              \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<N, 512>), dim3(B * A), dim3(512), lds2, stream, a);             \
+#define AT_LAUNCH1(N, M)                                                                                                \
+        if (dq_nt == 1024) hipLaunchKernelGGL((attn_bwd_dq_kernel<N, 1024, M>), dim3(B * A), dim3(1024), lds1, stream, a); \
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<N, 512, M>), dim3(B * A), dim3(512), lds1, stream, a);              \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<N, 512, M>), dim3(B * A), dim3(512), lds2, stream, a);
+#define AT_LAUNCH(N)                                  \
+    if (S == N * 16) {                                \
+        if (kv_len) { AT_LAUNCH1(N, true) }           \
+        else { AT_LAUNCH1(N, false) }                 \
     }
     AT_FOR_S(AT_LAUNCH)
+#undef AT_LAUNCH1
 #undef AT_LAUNCH
 #undef AT_FOR_S
     DTF_CHECK_LAUNCH();

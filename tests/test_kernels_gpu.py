@@ -780,3 +780,31 @@ def test_attention_backward_matches_reference(dev, B, S, A):
     x3 = qkv.clone().requires_grad_()
     att.attention_packed(x3).backward(do)
     assert torch.equal(x3.grad, x1.grad)
+
+
+def test_attention_key_padding_mask(dev):
+    from distributed_tensorflow_amd.ops import attention as att
+
+    torch.manual_seed(0)
+    B, S, A = 3, 256, 2
+    lens = torch.tensor([256, 100, 17], device=dev, dtype=torch.int32)
+    qkv = (torch.randn(B, S, 3, A, 64, device=dev) * 1.2).to(torch.bfloat16)
+    do = torch.randn(B, S, A * 64, device=dev).to(torch.bfloat16)
+    valid_q = (torch.arange(S, device=dev)[None, :] < lens[:, None])
+    do = do * valid_q[:, :, None]                 # padded query rows carry no gradient (as in BERT's loss)
+    x1 = qkv.clone().requires_grad_()
+    o1 = att.attention_packed(x1, lens)
+    o1.backward(do)
+    x2 = qkv.float().requires_grad_()
+    q, k, v = x2.permute(2, 0, 3, 1, 4).unbind(0)
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    s = s.masked_fill(~valid_q[:, None, None, :], float("-inf"))
+    o2 = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, A * 64)
+    o2.backward(do.float())
+    m = valid_q[:, :, None].float()
+    torch.testing.assert_close(o1.float() * m, o2 * m, rtol=2e-2, atol=2e-2)
+    g1, g2 = x1.grad.float(), x2.grad
+    assert float((g1 - g2).norm() / g2.norm()) < 0.02
+    # padded keys / values receive exactly zero gradient
+    pad = ~valid_q
+    assert float(g1[:, :, 1][pad].abs().max()) == 0.0 and float(g1[:, :, 2][pad].abs().max()) == 0.0
