@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct, bn_act_concat
-from ..ops.conv import Conv1x1
+from ..ops.conv import Conv1x1, Conv2dTN
 from ..ops.pool import avg_pool2d, max_pool2d
 
 
@@ -26,7 +26,7 @@ class ConvBN(nn.Module):
         if k == 1 and stride == 1 and padding == 0:
             self.conv = Conv1x1(i, o)     # NHWC 1x1 = GEMM (ops/conv.py picks the kernel per product)
         else:
-            self.conv = nn.Conv2d(i, o, k, stride=stride, padding=padding, bias=False)
+            self.conv = Conv2dTN(i, o, k, stride=stride, padding=padding, bias=False)
         self.bn = FusedBatchNormAct(o, relu=True, eps=1e-3)
 
     def forward(self, x):

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct
-from ..ops.conv import Conv1x1
+from ..ops.conv import Conv1x1, Conv2dTN
 from ..ops.pool import max_pool2d
 
 _DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
@@ -29,7 +29,7 @@ _DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 def _conv(i, o, k, stride=1):
     if k == 1 and stride == 1:
         return Conv1x1(i, o)          # NHWC 1x1 = GEMM: per-product kernel choice (ops/conv.py)
-    return nn.Conv2d(i, o, k, stride=stride, padding=k // 2, bias=False)
+    return Conv2dTN(i, o, k, stride=stride, padding=k // 2, bias=False)   # wide layers: K6T weight gradient
 
 
 class Bottleneck(nn.Module):

@@ -161,3 +161,110 @@ class Conv1x1(nn.Conv2d):
 
     def forward_fork(self, x, own_skip_grad=False):
         return conv1x1_fork(x, self.weight, own_skip_grad)
+
+
+# ---------------------------------------------------------------------------
+# general KH x KW convolutions: weight gradient through K6T with an implicit im2col gather
+# ---------------------------------------------------------------------------
+_wrw_declared = False
+_wrw_ws = {}
+_zero_page = {}
+_CONV_WRW = os.environ.get("DTF_CONV_WRW", "1") != "0"          # A/B switch
+# Measured against MIOpen's tuned solvers (scripts/conv_wrw_bench.py): K6T wins from 256 channels on both sides
+# (ResNet stage 3/4 3x3, Inception's 8x8 blocks) and loses on the narrow, spatially large layers.
+_CONV_WRW_MIN_CH = int(os.environ.get("DTF_CONV_WRW_MIN_CH", "256"))
+
+
+def _wrw_lib():
+    global _wrw_declared
+    import ctypes
+
+    from . import hip
+
+    lib = hip.lib()
+    if not _wrw_declared:
+        P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        hip.declare("dtf_conv_wrw_workspace", [L, I, I], L)
+        hip.declare("dtf_conv_wrw", [P, P, P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P])
+        _wrw_declared = True
+    return lib
+
+
+def conv_wrw_eligible(dy, x, weight, stride, padding, dilation=(1, 1), groups=1):
+    return (_CONV_WRW and x.is_cuda and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and x.dim() == 4 and groups == 1 and tuple(dilation) == (1, 1)
+            and stride[0] == stride[1] and x.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0
+            and weight.shape[1] * weight.shape[2] * weight.shape[3] >= 256
+            and x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last)
+            and weight.is_contiguous(memory_format=torch.channels_last)
+            and dy.shape[0] * dy.shape[2] * dy.shape[3] < (1 << 24))
+
+
+def conv_wrw_profitable(weight):
+    """Where the module form switches to K6T on its own (``conv_wrw`` itself runs any eligible shape)."""
+    return min(weight.shape[0], weight.shape[1]) >= _CONV_WRW_MIN_CH
+
+
+def conv_wrw(dy, x, weight, stride, padding):
+    """``dW`` of ``conv2d(x, weight, stride, padding)`` for NHWC bf16 tensors (K6T with per-lane im2col source
+    addresses: the patch matrix is never materialised, no fp32 workspace zero-fill / cast passes, no atomics:
+    bitwise reproducible).  Returns a channels-last ``[Cout, Cin, KH, KW]`` tensor like the weight."""
+    from . import hip
+
+    lib = _wrw_lib()
+    NB, Cin, H, W = x.shape
+    _, Cout, OH, OW = dy.shape
+    KH, KW = weight.shape[2], weight.shape[3]
+    dev = x.device
+    n = int(lib.dtf_conv_wrw_workspace(NB * OH * OW, Cout, KH * KW * Cin))
+    ws = _wrw_ws.get(dev)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=dev)
+        _wrw_ws[dev] = ws
+    z = _zero_page.get(dev)
+    if z is None:
+        z = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+        _zero_page[dev] = z
+    dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=dev)
+    rc = lib.dtf_conv_wrw(hip.ptr(dy), hip.ptr(x), hip.ptr(dw), hip.dt(dw), hip.ptr(ws), hip.ptr(z), NB, H, W, Cin, OH, OW,
+                          Cout, KH, KW, int(stride[0]), int(padding[0]), int(padding[1]), hip.stream())
+    hip.check(rc, "dtf_conv_wrw")
+    return dw.permute(0, 3, 1, 2)
+
+
+class _ConvFn(torch.autograd.Function):
+    """``conv2d`` whose weight gradient runs on K6T (MIOpen keeps forward and the data gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding):
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, padding)
+        return F.conv2d(x, weight, None, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, padding = ctx.geom
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        use_tn = (ctx.needs_input_grad[1] and conv_wrw_profitable(weight)
+                  and conv_wrw_eligible(dy, x, weight, stride, padding))
+        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not use_tn, False]
+        if mask[0] or mask[1]:
+            gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, list(stride), list(padding), [1, 1], False,
+                                                            [0, 0], 1, mask)
+            dx, dw = (gx if mask[0] else None), (gw if mask[1] else None)
+        if use_tn:
+            dw = conv_wrw(dy, x, weight, stride, padding)
+        return dx, dw, None, None
+
+
+class Conv2dTN(nn.Conv2d):
+    """``nn.Conv2d`` (bias-free, groups 1) with the K6T weight gradient where it is eligible."""
+
+    def forward(self, x):
+        if (self.bias is None and self.groups == 1 and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
+                and _CONV_WRW and isinstance(self.padding, tuple) and conv_wrw_profitable(self.weight)):
+            return _ConvFn.apply(x, self.weight, self.stride, self.padding)
+        return super().forward(x)

@@ -30,6 +30,12 @@ typedef const __attribute__((address_space(1))) void tn_glb_void;
 struct TnArgs {
     const unsigned short* A; const unsigned short* B; float* slab; float* bias_slab;
     int M, N, K; int ntn, ntk, splits, m_per_split;
+    // CONV variant (weight gradient of a KH x KW convolution, NHWC): B is the input image [NB, H, W, Cin] and
+    // the B operand row of output pixel m = (n, oh, ow) is its im2col patch, gathered by the per-lane LDS-DMA
+    // source addresses; K = KH * KW * Cin.  Out-of-image taps and rows >= M read a 16-byte zero page.
+    const unsigned short* zero;
+    int Cin, H, W, OH, OW, KW, stride, pad_h, pad_w;
+    float inv_ohw, inv_ow;
 };
 
 __device__ __forceinline__ int tn_xcd_remap(int bid, int nwg) {
@@ -55,7 +61,7 @@ __device__ __forceinline__ tn_s16x4 tn_tr_read_2k(unsigned addr) {
 // BIAS: also produce the column sums of A (the bias gradient sum_m dZ[m, n]) -- the waves of the first
 // column of k tiles multiply their A fragments by an all-ones B fragment (8 extra MFMAs per K step for
 // one wave in four of one block in ntk), which saves the separate pass over dZ.
-template <bool BIAS>
+template <bool BIAS, bool CONV>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     const int m_begin = split * a.m_per_split;
     int m_end = m_begin + a.m_per_split;
     if (m_end > a.M) m_end = a.M;
-    const int nk = m_end > m_begin ? (m_end - m_begin) >> 5 : 0;
+    const int nk = m_end > m_begin ? (m_end - m_begin + 31) >> 5 : 0;      // plain variant: M % 32 == 0
 
     // staging: wave w fills row pairs 2w, 2w+1 (1 KB = 2 rows x 512 B per instruction) of both images
     const unsigned short* pa[2];
@@ -86,12 +92,55 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
         pb[i] = a.B + (int64_t)(m_begin + row) * a.K + cb;
     }
     const int64_t stepA = (int64_t)32 * a.N, stepB = (int64_t)32 * a.K;
+    // CONV: per-lane constants of the im2col gather (the lane's k column never changes: k0 is per block)
+    int cv_row[2], cv_c[2], cv_dh[2], cv_dw[2], cv_ca[2];
+    bool cv_kvalid[2];
+    if (CONV) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 2 + (lane >> 5);
+            const int sx = (row & 3) | (((row >> 3) & 1) << 2);
+            const int col = ((((lane & 31) >> 1) ^ sx) << 4) + ((lane & 1) << 3);
+            const int k = k0 + col;
+            cv_kvalid[i] = k < a.K;
+            const int tap = k / a.Cin;
+            cv_c[i] = k - tap * a.Cin;
+            cv_dh[i] = tap / a.KW;
+            cv_dw[i] = tap - cv_dh[i] * a.KW;
+            cv_row[i] = row;
+            int ca = n0 + col;
+            if (ca > a.N - 8) ca = a.N - 8;
+            cv_ca[i] = ca;
+        }
+    }
     auto stage = [&](int t) {
         unsigned char* base = smem + (t & 3) * 32768 + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((tn_glb_void*)(pa[i] + t * stepA), (tn_lds_void*)(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((tn_glb_void*)(pb[i] + t * stepB), (tn_lds_void*)(base + 16384 + i * 1024), 16, 0, 0);
+            if (!CONV) {
+                __builtin_amdgcn_global_load_lds((tn_glb_void*)(pa[i] + t * stepA), (tn_lds_void*)(base + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((tn_glb_void*)(pb[i] + t * stepB), (tn_lds_void*)(base + 16384 + i * 1024), 16, 0, 0);
+            } else {
+                const int m = m_begin + t * 32 + cv_row[i];
+                const unsigned short* sa = a.zero;
+                const unsigned short* sb = a.zero;
+                if (m < a.M) {
+                    sa = a.A + (int64_t)m * a.N + cv_ca[i];
+                    // m -> (n, oh, ow): float reciprocal + one correction step (m < 2^24 checked on the host)
+                    const int ohw = a.OH * a.OW;
+                    int n = (int)((float)m * a.inv_ohw);
+                    int r = m - n * ohw;
+                    if (r < 0) { --n; r += ohw; } else if (r >= ohw) { ++n; r -= ohw; }
+                    int oh = (int)((float)r * a.inv_ow);
+                    int ow = r - oh * a.OW;
+                    if (ow < 0) { --oh; ow += a.OW; } else if (ow >= a.OW) { ++oh; ow -= a.OW; }
+                    const int ih = oh * a.stride - a.pad_h + cv_dh[i], iw = ow * a.stride - a.pad_w + cv_dw[i];
+                    if (cv_kvalid[i] && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                        sb = a.B + (((int64_t)n * a.H + ih) * a.W + iw) * a.Cin + cv_c[i];
+                }
+                __builtin_amdgcn_global_load_lds((tn_glb_void*)sa, (tn_lds_void*)(base + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((tn_glb_void*)sb, (tn_lds_void*)(base + 16384 + i * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -233,7 +282,7 @@ static inline void tn_plan(int M, int N, int K, int* ntn, int* ntk, int* splits,
     const int ntiles = *ntn * *ntk;
     int s = 256 / ntiles;
     if (s < 1) s = 1;
-    const int mt = M / 32;                       // reduction tiles
+    const int mt = (M + 31) / 32;                // reduction tiles
     if (s > mt / 4) s = mt / 4 > 0 ? mt / 4 : 1; // at least 4 tiles per split
     const int per = (mt + s - 1) / s;
     *mps = per * 32;
@@ -257,19 +306,20 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int out_dtype, void* dbia
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if ((M & 31) || (N & 7) || (K & 7)) return -60;
     if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)workspace)) & 15) return -16;
-    TnArgs a{(const unsigned short*)A, (const unsigned short*)B, workspace, nullptr, M, N, K, 0, 0, 0, 0};
+    TnArgs a{};
+    a.A = (const unsigned short*)A; a.B = (const unsigned short*)B; a.slab = workspace; a.M = M; a.N = N; a.K = K;
     tn_plan(M, N, K, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
     a.bias_slab = workspace + (int64_t)a.splits * N * K;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute((const void*)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
         attr_set = true;
     }
     if (dbias)
-        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
+        hipLaunchKernelGGL((gemm_tn_kernel<true, false>), dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
     else
-        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
+        hipLaunchKernelGGL((gemm_tn_kernel<false, false>), dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
     const int64_t n4 = (int64_t)N * K / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -288,6 +338,51 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int out_dtype, void* dbia
             hipLaunchKernelGGL((tn_reduce_kernel<DTF_F32>), dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, stream,
                                a.bias_slab, a.splits, b4, (int64_t)N, dbias);
     }
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// fp32 workspace (floats) for dtf_conv_wrw
+int64_t dtf_conv_wrw_workspace(int64_t M, int Cout, int Ktot) {
+    int ntn, ntk, splits, mps;
+    tn_plan((int)M, Cout, Ktot, &ntn, &ntk, &splits, &mps);
+    return (int64_t)splits * Cout * Ktot;
+}
+
+// Weight gradient of a 2-D convolution, NHWC bf16, groups = 1, dilation = 1:
+//   dW[Cout][KH][KW][Cin] = sum_{n, oh, ow} dY[n, oh, ow, Cout] * X[n, oh*stride - pad_h + kh, ow*stride - pad_w + kw, Cin]
+// dy: [NB, OH, OW, Cout]; x: [NB, H, W, Cin]; zero: >= 16 bytes of zeros in device memory.
+int dtf_conv_wrw(const void* dy, const void* x, void* dw, int out_dtype, float* workspace, const void* zero, int NB, int H,
+                 int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                 hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    const int64_t M64 = (int64_t)NB * OH * OW;
+    const int Ktot = KH * KW * Cin;
+    if (M64 <= 0 || M64 >= (1 << 24) || (Cin & 7) || (Cout & 7) || stride < 1) return -61;
+    if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)workspace) | ((uintptr_t)zero)) & 15) return -16;
+    const int M = (int)M64;
+    TnArgs a{};
+    a.A = (const unsigned short*)dy; a.B = (const unsigned short*)x; a.slab = workspace; a.M = M; a.N = Cout; a.K = Ktot;
+    tn_plan(M, Cout, Ktot, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
+    a.zero = (const unsigned short*)zero;
+    a.Cin = Cin; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
+    a.inv_ohw = 1.0f / (float)(OH * OW);
+    a.inv_ow = 1.0f / (float)OW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)gemm_tn_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_kernel<false, true>), dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
+    const int64_t n4 = (int64_t)Cout * Ktot / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (out_dtype == DTF_BF16)
+        hipLaunchKernelGGL((tn_reduce_kernel<DTF_BF16>), dim3((unsigned)blocks), dim3(256), 0, stream, workspace, a.splits,
+                           n4, (int64_t)Cout * Ktot, dw);
+    else
+        hipLaunchKernelGGL((tn_reduce_kernel<DTF_F32>), dim3((unsigned)blocks), dim3(256), 0, stream, workspace, a.splits,
+                           n4, (int64_t)Cout * Ktot, dw);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -808,3 +808,44 @@ def test_attention_key_padding_mask(dev):
     # padded keys / values receive exactly zero gradient
     pad = ~valid_q
     assert float(g1[:, :, 1][pad].abs().max()) == 0.0 and float(g1[:, :, 2][pad].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [
+    # NB, Cin, H, W, Cout, KH, KW, stride, pad
+    (4, 64, 14, 14, 128, 3, 3, 1, (1, 1)),
+    (3, 128, 15, 13, 256, 3, 3, 2, (1, 1)),
+    (2, 160, 17, 17, 192, 1, 7, 1, (0, 3)),
+    (2, 160, 17, 17, 160, 7, 1, 1, (3, 0)),
+    (2, 48, 12, 12, 128, 5, 5, 1, (2, 2)),
+    (5, 256, 7, 7, 512, 3, 3, 1, (1, 1)),
+    (2, 288, 19, 19, 384, 3, 3, 2, (0, 0)),
+])
+def test_conv_wrw_matches_reference(dev, cfg, monkeypatch):
+    from distributed_tensorflow_amd.ops import conv
+
+    monkeypatch.setattr(conv, "_CONV_WRW_MIN_CH", 8)            # exercise K6T through the module at every test shape
+
+    NB, Cin, H, W, Cout, KH, KW, stride, pad = cfg
+    torch.manual_seed(0)
+    x = torch.randn(NB, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, KH, KW, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x2, w2 = x.float().requires_grad_(), w.float().requires_grad_()
+    y2 = torch.nn.functional.conv2d(x2, w2, None, stride, pad)
+    dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y2.backward(dy.float())
+    assert conv.conv_wrw_eligible(dy, x, w, (stride, stride), pad)
+    dw = conv.conv_wrw(dy, x, w, (stride, stride), pad)
+    assert dw.shape == w.shape and dw.is_contiguous(memory_format=torch.channels_last)
+    ref = w2.grad
+    assert float((dw.float() - ref).norm() / ref.norm()) < 1e-2
+    torch.testing.assert_close(dw.float(), ref, rtol=3e-2, atol=0.02 * float(ref.abs().max()))
+    assert torch.equal(conv.conv_wrw(dy, x, w, (stride, stride), pad), dw)          # deterministic
+    # through the module
+    m = conv.Conv2dTN(Cin, Cout, (KH, KW), stride=stride, padding=pad, bias=False).to(dev).to(torch.bfloat16)
+    m = m.to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        m.weight.copy_(w)
+    x3 = x.clone().requires_grad_()
+    m(x3).backward(dy)
+    assert float((m.weight.grad.float() - ref).norm() / ref.norm()) < 1e-2
+    assert float((x3.grad.float() - x2.grad).norm() / x2.grad.norm()) < 2e-2
