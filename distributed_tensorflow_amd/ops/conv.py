@@ -169,10 +169,11 @@ class Conv1x1(nn.Conv2d):
 _wrw_declared = False
 _wrw_ws = {}
 _zero_page = {}
+_wrw_tab = {}
 _CONV_WRW = os.environ.get("DTF_CONV_WRW", "1") != "0"          # A/B switch
-# Measured against MIOpen's tuned solvers (scripts/conv_wrw_bench.py): K6T wins from 256 channels on both sides
+# Measured against MIOpen's tuned solvers (scripts/conv_wrw_bench.py): K6T wins from 160 channels on both sides
 # (ResNet stage 3/4 3x3, Inception's 8x8 blocks) and loses on the narrow, spatially large layers.
-_CONV_WRW_MIN_CH = int(os.environ.get("DTF_CONV_WRW_MIN_CH", "256"))
+_CONV_WRW_MIN_CH = int(os.environ.get("DTF_CONV_WRW_MIN_CH", "160"))
 
 
 def _wrw_lib():
@@ -185,7 +186,9 @@ def _wrw_lib():
     if not _wrw_declared:
         P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
         hip.declare("dtf_conv_wrw_workspace", [L, I, I], L)
-        hip.declare("dtf_conv_wrw", [P, P, P, I, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P])
+        hip.declare("dtf_conv_wrw_table_ints", [L], L)
+        hip.declare("dtf_conv_wrw_table", [P, I, I, I, I, I, I, I, I, P])
+        hip.declare("dtf_conv_wrw", [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P])
         _wrw_declared = True
     return lib
 
@@ -225,9 +228,15 @@ def conv_wrw(dy, x, weight, stride, padding):
     if z is None:
         z = torch.zeros(64, dtype=torch.bfloat16, device=dev)
         _zero_page[dev] = z
+    geom = (dev, NB, H, W, OH, OW, int(stride[0]), int(padding[0]), int(padding[1]))
+    tab = _wrw_tab.get(geom)
+    if tab is None:           # output pixel -> patch origin, once per layer geometry
+        tab = torch.empty(int(lib.dtf_conv_wrw_table_ints(NB * OH * OW)), dtype=torch.int32, device=dev)
+        hip.check(lib.dtf_conv_wrw_table(hip.ptr(tab), *geom[1:], hip.stream()), "dtf_conv_wrw_table")
+        _wrw_tab[geom] = tab
     dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=dev)
-    rc = lib.dtf_conv_wrw(hip.ptr(dy), hip.ptr(x), hip.ptr(dw), hip.dt(dw), hip.ptr(ws), hip.ptr(z), NB, H, W, Cin, OH, OW,
-                          Cout, KH, KW, int(stride[0]), int(padding[0]), int(padding[1]), hip.stream())
+    rc = lib.dtf_conv_wrw(hip.ptr(dy), hip.ptr(x), hip.ptr(dw), hip.dt(dw), hip.ptr(ws), hip.ptr(z), hip.ptr(tab), NB, H, W,
+                          Cin, OH, OW, Cout, KH, KW, hip.stream())
     hip.check(rc, "dtf_conv_wrw")
     return dw.permute(0, 3, 1, 2)
 

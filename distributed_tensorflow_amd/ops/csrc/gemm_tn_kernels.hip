@@ -20,6 +20,7 @@
 //     slab, a second kernel adds the slabs in fixed order (deterministic) and rounds once to bf16.
 // Requirements: M % 32 == 0, N % 8 == 0, K % 8 == 0.
 #include "dtf_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) short tn_s16x8;
 typedef __attribute__((ext_vector_type(4))) short tn_s16x4;
@@ -33,10 +34,16 @@ struct TnArgs {
     // CONV variant (weight gradient of a KH x KW convolution, NHWC): B is the input image [NB, H, W, Cin] and
     // the B operand row of output pixel m = (n, oh, ow) is its im2col patch, gathered by the per-lane LDS-DMA
     // source addresses; K = KH * KW * Cin.  Out-of-image taps and rows >= M read a 16-byte zero page.
+    // The m -> (n, oh, ow) decomposition is a per-geometry table (conv_tab_kernel): entry m = { pixel index of the
+    // patch origin (n*H + oh*stride - pad_h)*W + ow*stride - pad_w, origin row | origin column << 16 }; a wave
+    // fetches the four entries of its four rows per K step with one scalar load.
     const unsigned short* zero;
-    int Cin, H, W, OH, OW, KW, stride, pad_h, pad_w;
-    float inv_ohw, inv_ow;
+    const int* tab;
+    int Cin, H, W, KW;
 };
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef const __attribute__((address_space(4))) i32x4 tn_const_i32x4;
 
 __device__ __forceinline__ int tn_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, pos = bid >> 3;
@@ -61,7 +68,9 @@ __device__ __forceinline__ tn_s16x4 tn_tr_read_2k(unsigned addr) {
 // BIAS: also produce the column sums of A (the bias gradient sum_m dZ[m, n]) -- the waves of the first
 // column of k tiles multiply their A fragments by an all-ones B fragment (8 extra MFMAs per K step for
 // one wave in four of one block in ntk), which saves the separate pass over dZ.
-template <bool BIAS, bool CONV>
+// NI: 16-row A fragments per wave -- the block's n extent is 32 * NI (256, 192, 128 or 64 output rows), chosen on
+// the host so that narrow N (Cout of a convolution) does not pay for a 256-row tile.
+template <bool BIAS, bool CONV, int NI>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,7 +80,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     const int ntiles = a.ntn * a.ntk;
     const int split = bid / ntiles, tile = bid - split * ntiles;
     const int tn = tile / a.ntk, tk = tile - tn * a.ntk;
-    const int n0 = tn * 256, k0 = tk * 256;
+    const int n0 = tn * (32 * NI), k0 = tk * 256;
     const int m_begin = split * a.m_per_split;
     int m_end = m_begin + a.m_per_split;
     if (m_end > a.M) m_end = a.M;
@@ -93,27 +102,30 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     }
     const int64_t stepA = (int64_t)32 * a.N, stepB = (int64_t)32 * a.K;
     // CONV: per-lane constants of the im2col gather (the lane's k column never changes: k0 is per block)
-    int cv_row[2], cv_c[2], cv_dh[2], cv_dw[2], cv_ca[2];
+    int cv_dh[2], cv_dw[2], cv_off[2];
     bool cv_kvalid[2];
+    const int half = lane >> 5;
     if (CONV) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int row = (wave * 2 + i) * 2 + (lane >> 5);
+            const int row = (wave * 2 + i) * 2 + half;
             const int sx = (row & 3) | (((row >> 3) & 1) << 2);
             const int col = ((((lane & 31) >> 1) ^ sx) << 4) + ((lane & 1) << 3);
             const int k = k0 + col;
             cv_kvalid[i] = k < a.K;
             const int tap = k / a.Cin;
-            cv_c[i] = k - tap * a.Cin;
             cv_dh[i] = tap / a.KW;
             cv_dw[i] = tap - cv_dh[i] * a.KW;
-            cv_row[i] = row;
-            int ca = n0 + col;
-            if (ca > a.N - 8) ca = a.N - 8;
-            cv_ca[i] = ca;
+            cv_off[i] = (cv_dh[i] * a.W + cv_dw[i]) * a.Cin + (k - tap * a.Cin);
         }
     }
-    auto stage = [&](int t) {
+    // table entries of the wave's rows 4 w .. 4 w + 3 of reduction tile t: 32 B, one scalar load pair
+    auto load_tab = [&](int t, i32x4& e01, i32x4& e23) {
+        tn_const_i32x4* tp = (tn_const_i32x4*)(uintptr_t)(a.tab + (int64_t)(m_begin + t * 32 + wave * 4) * 2);
+        e01 = tp[0];
+        e23 = tp[1];
+    };
+    auto stage = [&](int t, const i32x4& e01, const i32x4& e23) {
         unsigned char* base = smem + (t & 3) * 32768 + wave * 2048;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -121,22 +133,15 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
                 __builtin_amdgcn_global_load_lds((tn_glb_void*)(pa[i] + t * stepA), (tn_lds_void*)(base + i * 1024), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((tn_glb_void*)(pb[i] + t * stepB), (tn_lds_void*)(base + 16384 + i * 1024), 16, 0, 0);
             } else {
-                const int m = m_begin + t * 32 + cv_row[i];
-                const unsigned short* sa = a.zero;
-                const unsigned short* sb = a.zero;
-                if (m < a.M) {
-                    sa = a.A + (int64_t)m * a.N + cv_ca[i];
-                    // m -> (n, oh, ow): float reciprocal + one correction step (m < 2^24 checked on the host)
-                    const int ohw = a.OH * a.OW;
-                    int n = (int)((float)m * a.inv_ohw);
-                    int r = m - n * ohw;
-                    if (r < 0) { --n; r += ohw; } else if (r >= ohw) { ++n; r -= ohw; }
-                    int oh = (int)((float)r * a.inv_ow);
-                    int ow = r - oh * a.OW;
-                    if (ow < 0) { --oh; ow += a.OW; } else if (ow >= a.OW) { ++oh; ow -= a.OW; }
-                    const int ih = oh * a.stride - a.pad_h + cv_dh[i], iw = ow * a.stride - a.pad_w + cv_dw[i];
-                    if (cv_kvalid[i] && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-                        sb = a.B + (((int64_t)n * a.H + ih) * a.W + iw) * a.Cin + cv_c[i];
+                const i32x4 e = i == 0 ? e01 : e23;
+                const int pix = half ? e[2] : e[0];
+                const int org = half ? e[3] : e[1];
+                const int ih = (int)(short)(org & 0xffff) + cv_dh[i], iw = (org >> 16) + cv_dw[i];
+                const unsigned short* sa = pa[i] + t * stepA;
+                const unsigned short* sb = a.B + ((int64_t)pix * a.Cin + cv_off[i]);
+                if (!(cv_kvalid[i] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W)) sb = a.zero;
+                if (m_begin + t * 32 + 32 > a.M) {          // uniform: only the last tile of the last split
+                    if (m_begin + t * 32 + (wave * 2 + i) * 2 + half >= a.M) { sa = a.zero; sb = a.zero; }
                 }
                 __builtin_amdgcn_global_load_lds((tn_glb_void*)sa, (tn_lds_void*)(base + i * 1024), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds((tn_glb_void*)sb, (tn_lds_void*)(base + 16384 + i * 1024), 16, 0, 0);
@@ -144,14 +149,14 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
         }
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[NI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 bacc[8];
+    f32x4 bacc[NI];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NI; ++i) bacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool do_bias = BIAS && wc == 0 && tk == 0;
     tn_s16x8 ones;
 #pragma unroll
@@ -163,9 +168,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     const int sx = q | ((g & 1) << 2);
     const unsigned lds0 = (unsigned)(uintptr_t)(tn_lds_void*)smem;
     const int row_off = (int)lds0 + (g * 8 + q) * 512 + p * 8;        // h = 0; h = 1 adds 4 rows = 2048 B
-    int offA[8], offB[4];
+    int offA[NI], offB[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) offA[i] = row_off + (((wr * 8 + i) ^ sx) << 5);
+    for (int i = 0; i < NI; ++i) offA[i] = row_off + (((wr * NI + i) ^ sx) << 5);
 #pragma unroll
     for (int j = 0; j < 4; ++j) offB[j] = row_off + 16384 + (((wc * 4 + j) ^ sx) << 5);
 
@@ -178,10 +183,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
         else if (n_out == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        \
     } while (0)
+    i32x4 e01 = {0, 0, 0, 0}, e23 = {0, 0, 0, 0};
     if (nk > 0) {
-        stage(0);
-        if (nk > 1) stage(1);
-        if (nk > 2) stage(2);
+        if (CONV) load_tab(0, e01, e23);
+        stage(0, e01, e23);
+        if (nk > 1) { if (CONV) load_tab(1, e01, e23); stage(1, e01, e23); }
+        if (nk > 2) { if (CONV) load_tab(2, e01, e23); stage(2, e01, e23); }
+        if (CONV && nk > 3) load_tab(3, e01, e23);
         if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -189,16 +197,19 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave of every SIMD
     for (int t = 0; t < nk; ++t) {
-        if (t + 3 < nk) stage(t + 3);
+        if (t + 3 < nk) {
+            stage(t + 3, e01, e23);
+            if (CONV && t + 4 < nk) load_tab(t + 4, e01, e23);       // consumed one iteration later
+        }
         const unsigned img = (unsigned)((t & 3) * 32768);
-        tn_s16x4 la[8], ha[8], lb[4], hb[4];
+        tn_s16x4 la[NI], ha[NI], lb[4], hb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             lb[j] = tn_tr_read(img + offB[j]);
             hb[j] = tn_tr_read_2k(img + offB[j]);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NI; ++i) {
             la[i] = tn_tr_read(img + offA[i]);
             ha[i] = tn_tr_read_2k(img + offA[i]);
         }
@@ -207,20 +218,20 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        tn_s16x8 fa[8], fb[4];
+        tn_s16x8 fa[NI], fb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = __builtin_shufflevector(lb[j], hb[j], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = __builtin_shufflevector(la[i], ha[i], 0, 1, 2, 3, 4, 5, 6, 7);
+        for (int i = 0; i < NI; ++i) fa[i] = __builtin_shufflevector(la[i], ha[i], 0, 1, 2, 3, 4, 5, 6, 7);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         if (BIAS && do_bias) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, bacc[i], 0, 0, 0);
+            for (int i = 0; i < NI; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, bacc[i], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         if (wr == 0) TN_WAIT_NEXT(t);
@@ -235,10 +246,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     float* out = a.slab + (int64_t)split * a.N * a.K;
     const int fr = lane & 15;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wr * 128 + i * 16 + g * 4 + r;
+            const int n = n0 + wr * (16 * NI) + i * 16 + g * 4 + r;
             if (n >= a.N) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -249,10 +260,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
     if (BIAS && do_bias && fr == 0) {        // every column of bacc holds the row sums; column 0 stores them
         float* bo = a.bias_slab + (int64_t)split * a.N;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wr * 128 + i * 16 + g * 4 + r;
+                const int n = n0 + wr * (16 * NI) + i * 16 + g * 4 + r;
                 if (n < a.N) bo[n] = bacc[i][r];
             }
     }
@@ -276,8 +287,27 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
-static inline void tn_plan(int M, int N, int K, int* ntn, int* ntk, int* splits, int* mps) {
-    *ntn = (N + 255) / 256;
+// n extent of the block tile: 32 * NI rows, NI in {8, 6, 4, 2}.  Cost model per reduction step: NI fragments of
+// MFMA work plus a fixed ~1.5 fragments for the B reads / staging that do not shrink with NI.
+static inline int tn_pick_ni(int N) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("DTF_TN_NI");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 2 || forced == 4 || forced == 6 || forced == 8) return forced;
+    int best = 8;
+    float best_cost = 1e30f;
+    for (int ni = 8; ni >= 2; ni -= 2) {
+        const float cost = (float)((N + 32 * ni - 1) / (32 * ni)) * ((float)ni + 1.5f);
+        if (cost < best_cost - 1e-3f) { best_cost = cost; best = ni; }
+    }
+    return best;
+}
+
+static inline void tn_plan(int M, int N, int K, int* ni, int* ntn, int* ntk, int* splits, int* mps) {
+    *ni = tn_pick_ni(N);
+    *ntn = (N + 32 * *ni - 1) / (32 * *ni);
     *ntk = (K + 255) / 256;
     const int ntiles = *ntn * *ntk;
     int s = 256 / ntiles;
@@ -289,12 +319,59 @@ static inline void tn_plan(int M, int N, int K, int* ntn, int* ntk, int* splits,
     *splits = (mt + per - 1) / per;
 }
 
+// table of the CONV variant (see TnArgs); entries M .. roundup(M, 32) - 1 never pass the bounds test
+__global__ __launch_bounds__(256) void conv_tab_kernel(int* __restrict__ tab, int M, int Mpad, int H, int W, int OH, int OW,
+                                                       int stride, int pad_h, int pad_w) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= Mpad) return;
+    int pix = 0, org = (int)0x80008000u;
+    if (m < M) {
+        const int n = m / (OH * OW), r = m - n * (OH * OW);
+        const int oh = r / OW, ow = r - oh * OW;
+        const int ih0 = oh * stride - pad_h, iw0 = ow * stride - pad_w;
+        pix = (n * H + ih0) * W + iw0;
+        org = (ih0 & 0xffff) | (iw0 << 16);
+    }
+    tab[2 * m] = pix;
+    tab[2 * m + 1] = org;
+}
+
+template <bool BIAS, bool CONV>
+static void tn_launch(const TnArgs& a, int ni, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<BIAS, CONV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<BIAS, CONV, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<BIAS, CONV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<BIAS, CONV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_set = true;
+    }
+    const dim3 grid(a.ntn * a.ntk * a.splits), block(512);
+    switch (ni) {
+    case 8: hipLaunchKernelGGL((gemm_tn_kernel<BIAS, CONV, 8>), grid, block, 131072, stream, a); break;
+    case 6: hipLaunchKernelGGL((gemm_tn_kernel<BIAS, CONV, 6>), grid, block, 131072, stream, a); break;
+    case 4: hipLaunchKernelGGL((gemm_tn_kernel<BIAS, CONV, 4>), grid, block, 131072, stream, a); break;
+    default: hipLaunchKernelGGL((gemm_tn_kernel<BIAS, CONV, 2>), grid, block, 131072, stream, a); break;
+    }
+}
+
+static void tn_reduce_launch(const float* slab, int splits, int64_t n, void* out, int out_dtype, hipStream_t stream) {
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (out_dtype == DTF_BF16)
+        hipLaunchKernelGGL((tn_reduce_kernel<DTF_BF16>), dim3((unsigned)blocks), dim3(256), 0, stream, slab, splits, n4, n, out);
+    else
+        hipLaunchKernelGGL((tn_reduce_kernel<DTF_F32>), dim3((unsigned)blocks), dim3(256), 0, stream, slab, splits, n4, n, out);
+}
+
 extern "C" {
 
 // fp32 workspace (floats) for dtf_gemm_tn: the dW slabs, then the bias slabs
 int64_t dtf_gemm_tn_workspace(int M, int N, int K) {
-    int ntn, ntk, splits, mps;
-    tn_plan(M, N, K, &ntn, &ntk, &splits, &mps);
+    int ni, ntn, ntk, splits, mps;
+    tn_plan(M, N, K, &ni, &ntn, &ntk, &splits, &mps);
     return (int64_t)splits * N * K + (int64_t)splits * N;
 }
 
@@ -307,82 +384,63 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int out_dtype, void* dbia
     if ((M & 31) || (N & 7) || (K & 7)) return -60;
     if ((((uintptr_t)A) | ((uintptr_t)B) | ((uintptr_t)C) | ((uintptr_t)workspace)) & 15) return -16;
     TnArgs a{};
+    int ni;
     a.A = (const unsigned short*)A; a.B = (const unsigned short*)B; a.slab = workspace; a.M = M; a.N = N; a.K = K;
-    tn_plan(M, N, K, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
+    tn_plan(M, N, K, &ni, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
     a.bias_slab = workspace + (int64_t)a.splits * N * K;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_tn_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        hipFuncSetAttribute((const void*)gemm_tn_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        attr_set = true;
-    }
-    if (dbias)
-        hipLaunchKernelGGL((gemm_tn_kernel<true, false>), dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<false, false>), dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
-    const int64_t n4 = (int64_t)N * K / 4;
-    int64_t blocks = (n4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (out_dtype == DTF_BF16)
-        hipLaunchKernelGGL((tn_reduce_kernel<DTF_BF16>), dim3((unsigned)blocks), dim3(256), 0, stream, workspace, a.splits,
-                           n4, (int64_t)N * K, C);
-    else
-        hipLaunchKernelGGL((tn_reduce_kernel<DTF_F32>), dim3((unsigned)blocks), dim3(256), 0, stream, workspace, a.splits,
-                           n4, (int64_t)N * K, C);
-    if (dbias) {
-        const int64_t b4 = N / 4;
-        if (bias_dtype == DTF_BF16)
-            hipLaunchKernelGGL((tn_reduce_kernel<DTF_BF16>), dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, stream,
-                               a.bias_slab, a.splits, b4, (int64_t)N, dbias);
-        else
-            hipLaunchKernelGGL((tn_reduce_kernel<DTF_F32>), dim3((unsigned)((b4 + 255) / 256)), dim3(256), 0, stream,
-                               a.bias_slab, a.splits, b4, (int64_t)N, dbias);
-    }
+    if (dbias) tn_launch<true, false>(a, ni, stream);
+    else tn_launch<false, false>(a, ni, stream);
+    tn_reduce_launch(workspace, a.splits, (int64_t)N * K, C, out_dtype, stream);
+    if (dbias) tn_reduce_launch(a.bias_slab, a.splits, (int64_t)N, dbias, bias_dtype, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }
 
 // fp32 workspace (floats) for dtf_conv_wrw
 int64_t dtf_conv_wrw_workspace(int64_t M, int Cout, int Ktot) {
-    int ntn, ntk, splits, mps;
-    tn_plan((int)M, Cout, Ktot, &ntn, &ntk, &splits, &mps);
+    int ni, ntn, ntk, splits, mps;
+    tn_plan((int)M, Cout, Ktot, &ni, &ntn, &ntk, &splits, &mps);
     return (int64_t)splits * Cout * Ktot;
+}
+
+// ints of the geometry table of dtf_conv_wrw (2 per output pixel, padded to whole reduction tiles)
+int64_t dtf_conv_wrw_table_ints(int64_t M) { return ((M + 31) / 32 * 32) * 2; }
+
+// fills the table; it depends on the geometry only, so the caller builds it once per layer shape
+int dtf_conv_wrw_table(void* tab, int NB, int H, int W, int OH, int OW, int stride, int pad_h, int pad_w, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    const int64_t M64 = (int64_t)NB * OH * OW;
+    if (M64 <= 0 || M64 >= (1 << 24) || (int64_t)NB * H * W >= (1ll << 31) || H >= 32768 || W >= 32768 || stride < 1) return -61;
+    if (((uintptr_t)tab) & 31) return -16;
+    const int M = (int)M64, Mpad = (M + 31) / 32 * 32;
+    hipLaunchKernelGGL(conv_tab_kernel, dim3((Mpad + 255) / 256), dim3(256), 0, stream, (int*)tab, M, Mpad, H, W, OH, OW, stride,
+                       pad_h, pad_w);
+    DTF_CHECK_LAUNCH();
+    return 0;
 }
 
 // Weight gradient of a 2-D convolution, NHWC bf16, groups = 1, dilation = 1:
 //   dW[Cout][KH][KW][Cin] = sum_{n, oh, ow} dY[n, oh, ow, Cout] * X[n, oh*stride - pad_h + kh, ow*stride - pad_w + kw, Cin]
-// dy: [NB, OH, OW, Cout]; x: [NB, H, W, Cin]; zero: >= 16 bytes of zeros in device memory.
-int dtf_conv_wrw(const void* dy, const void* x, void* dw, int out_dtype, float* workspace, const void* zero, int NB, int H,
-                 int W, int Cin, int OH, int OW, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
-                 hipStream_t stream) {
+// dy: [NB, OH, OW, Cout]; x: [NB, H, W, Cin]; zero: >= 16 bytes of zeros in device memory; tab: dtf_conv_wrw_table
+// of the same geometry.
+int dtf_conv_wrw(const void* dy, const void* x, void* dw, int out_dtype, float* workspace, const void* zero, const void* tab,
+                 int NB, int H, int W, int Cin, int OH, int OW, int Cout, int KH, int KW, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     const int64_t M64 = (int64_t)NB * OH * OW;
     const int Ktot = KH * KW * Cin;
-    if (M64 <= 0 || M64 >= (1 << 24) || (Cin & 7) || (Cout & 7) || stride < 1) return -61;
-    if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)workspace) | ((uintptr_t)zero)) & 15) return -16;
+    if (M64 <= 0 || M64 >= (1 << 24) || (Cin & 7) || (Cout & 7)) return -61;
+    if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)workspace) | ((uintptr_t)zero) | ((uintptr_t)tab)) & 15)
+        return -16;
     const int M = (int)M64;
     TnArgs a{};
+    int ni;
     a.A = (const unsigned short*)dy; a.B = (const unsigned short*)x; a.slab = workspace; a.M = M; a.N = Cout; a.K = Ktot;
-    tn_plan(M, Cout, Ktot, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
+    tn_plan(M, Cout, Ktot, &ni, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
     a.zero = (const unsigned short*)zero;
-    a.Cin = Cin; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
-    a.inv_ohw = 1.0f / (float)(OH * OW);
-    a.inv_ow = 1.0f / (float)OW;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_tn_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_tn_kernel<false, true>), dim3(a.ntn * a.ntk * a.splits), dim3(512), 131072, stream, a);
-    const int64_t n4 = (int64_t)Cout * Ktot / 4;
-    int64_t blocks = (n4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (out_dtype == DTF_BF16)
-        hipLaunchKernelGGL((tn_reduce_kernel<DTF_BF16>), dim3((unsigned)blocks), dim3(256), 0, stream, workspace, a.splits,
-                           n4, (int64_t)Cout * Ktot, dw);
-    else
-        hipLaunchKernelGGL((tn_reduce_kernel<DTF_F32>), dim3((unsigned)blocks), dim3(256), 0, stream, workspace, a.splits,
-                           n4, (int64_t)Cout * Ktot, dw);
+    a.tab = (const int*)tab;
+    a.Cin = Cin; a.H = H; a.W = W; a.KW = KW;
+    tn_launch<false, true>(a, ni, stream);
+    tn_reduce_launch(workspace, a.splits, (int64_t)Cout * Ktot, dw, out_dtype, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -688,7 +688,7 @@ def test_gemm_tn_identity_layout(dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(4096, 768, 768), (1024, 264, 520), (32768, 3072, 768), (1056, 8, 8), (2048, 256, 256),
-                                   (12544, 2048, 512), (1120, 304, 1000)])
+                                   (12544, 2048, 512), (1120, 304, 1000), (2048, 96, 576), (1024, 128, 264), (4096, 64, 64)])
 def test_gemm_tn_matches_reference(dev, M, N, K):
     torch.manual_seed(0)
     a = torch.randn(M, N, device=dev).to(torch.bfloat16)
@@ -821,6 +821,8 @@ def test_attention_key_padding_mask(dev):
     (2, 48, 12, 12, 128, 5, 5, 1, (2, 2)),
     (5, 256, 7, 7, 512, 3, 3, 1, (1, 1)),
     (2, 288, 19, 19, 384, 3, 3, 2, (0, 0)),
+    (3, 64, 20, 20, 64, 3, 3, 1, (1, 1)),
+    (2, 96, 11, 11, 96, 3, 3, 1, (1, 1)),
 ])
 def test_conv_wrw_matches_reference(dev, cfg, monkeypatch):
     from distributed_tensorflow_amd.ops import conv
