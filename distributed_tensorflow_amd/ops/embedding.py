@@ -7,6 +7,7 @@ X3/X4).  ``*_reference`` are the PyTorch definitions (CPU path + test oracle).
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -15,6 +16,7 @@ from . import hip
 SGD, ADAGRAD, ROWWISE_ADAGRAD = 0, 1, 2
 _OPT = {"sgd": SGD, "adagrad": ADAGRAD, "rowwise_adagrad": ROWWISE_ADAGRAD}
 _declared = False
+_PLAN_KERNEL = os.environ.get("DTF_EMB_PLAN_KERNEL", "1") != "0"      # A/B switch: 0 = framework-op segment plan
 
 
 def _lib():
@@ -26,6 +28,8 @@ def _lib():
         hip.declare("dtf_embedding_sparse_apply", [P, I, P, P, I, P, P, P, P, P, P, P, L, I, I, L, I, F, F, F, F, P])
         hip.declare("dtf_embedding_sgd_atomic", [P, P, P, I, L, I, I, L, F, F, P])
         hip.declare("dtf_embedding_chunk_rows", [])
+        hip.declare("dtf_embedding_plan_scratch_ints", [L], L)
+        hip.declare("dtf_embedding_segment_plan", [P, L, I, P, P, P, P, P, P])
         _declared = True
     return lib
 
@@ -93,10 +97,29 @@ def sparse_apply_reference(table, acc, idx, grad, opt="sgd", lr=0.01, eps=1e-10,
 
 def segment_plan(idx, chunk):
     """Sort ids and describe their runs with fixed-size tensors (no host sync):
-    ``sorted_ids, perm, chunk_begin[n+1], seg_begin[n+1], seg_first_chunk[n+1], nchunks[1]``."""
+    ``sorted_ids, perm, chunk_begin[n+1], seg_begin[n+1], seg_first_chunk[n+1], nchunks[1]``.
+    On the GPU the run / chunk boundaries come from the plan kernels of ``embedding_kernels.hip``."""
     n = idx.numel()
     dev = idx.device
     sid, perm = torch.sort(idx.reshape(-1), stable=True)
+    if idx.is_cuda and _PLAN_KERNEL and 0 < n < (1 << 31) - 4096:
+        lib = _lib()
+        scratch = torch.empty(int(lib.dtf_embedding_plan_scratch_ints(n)), dtype=torch.int32, device=dev)
+        out = torch.empty(3 * (n + 1) + 1, dtype=torch.int64, device=dev)
+        chunk_begin, seg_begin, seg_first_chunk = out[:n + 1], out[n + 1:2 * n + 2], out[2 * n + 2:3 * n + 3]
+        nchunks = out[3 * n + 3:]
+        rc = lib.dtf_embedding_segment_plan(hip.ptr(sid), n, int(chunk), hip.ptr(scratch), hip.ptr(chunk_begin),
+                                            hip.ptr(seg_begin), hip.ptr(seg_first_chunk), hip.ptr(nchunks), hip.stream())
+        hip.check(rc, "dtf_embedding_segment_plan")
+        return sid, perm, chunk_begin, seg_begin, seg_first_chunk, nchunks
+    return (sid, perm) + segment_plan_reference(sid, chunk)
+
+
+def segment_plan_reference(sid, chunk):
+    """The same boundaries with framework ops (CPU path, test oracle): ``chunk_begin, seg_begin,
+    seg_first_chunk, nchunks`` of the sorted ids ``sid``."""
+    n = sid.numel()
+    dev = sid.device
     pos = torch.arange(n, device=dev)
     head = torch.ones(n, dtype=torch.bool, device=dev)
     head[1:] = sid[1:] != sid[:-1]
@@ -111,7 +134,7 @@ def segment_plan(idx, chunk):
     chunk_begin = big.clone().scatter_reduce_(0, chunk_id, pos, "amin")
     seg_first_chunk = big.clone().scatter_reduce_(0, seg_id, chunk_id, "amin")
     nchunks = (chunk_id[-1:] + 1).contiguous()
-    return sid, perm, chunk_begin, seg_begin, seg_first_chunk, nchunks
+    return chunk_begin, seg_begin, seg_first_chunk, nchunks
 
 
 _ws = {}

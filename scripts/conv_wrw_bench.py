@@ -41,8 +41,14 @@ for NB, Cin, H, W, Cout, KH, KW, st, pad, cnt in SHAPES:
     r = {"Cin": Cin, "HW": H, "Cout": Cout, "k": "%dx%d" % (KH, KW), "s": st, "count": cnt}
     r["miopen"] = round(timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], list(pad), [1, 1], False, [0, 0], 1, [False, True, False])), 1)
     r["k6t"] = round(timeit(lambda: conv.conv_wrw(dy, x, w, (st, st), pad)), 1)
+    if os.environ.get("DTF_BENCH_FWD_DGRAD"):
+        r["fwd"] = round(timeit(lambda: torch.nn.functional.conv2d(x, w, None, st, pad)), 1)
+        r["dgrad"] = round(timeit(lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [st, st], list(pad), [1, 1], False, [0, 0], 1, [True, False, False])), 1)
     flops = 2.0 * dy.shape[0] * dy.shape[2] * dy.shape[3] * Cout * Cin * KH * KW
     r["k6t_TF"] = round(flops / r["k6t"] / 1e6, 0)
+    if "fwd" in r:
+        r["fwd_TF"] = round(flops / r["fwd"] / 1e6, 0)
+        r["dgrad_TF"] = round(flops / r["dgrad"] / 1e6, 0)
     tot["miopen"] += r["miopen"] * cnt; tot["k6t"] += r["k6t"] * cnt; tot["best"] += min(r["miopen"], r["k6t"]) * cnt
     print(json.dumps(r), flush=True)
 print(json.dumps({k: round(v, 1) for k, v in tot.items()}))

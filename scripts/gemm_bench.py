@@ -9,6 +9,8 @@ dev = torch.device("cuda")
 shapes = [(8192, 768, 768), (8192, 3072, 768), (8192, 768, 3072), (32768, 768, 768), (32768, 2304, 768), (32768, 3072, 768),
           (32768, 768, 3072), (65536, 1024, 1672), (65536, 512, 1024), (4096, 4096, 4096), (8192, 8192, 8192),
           (802816, 256, 64)]
+if os.environ.get("DTF_GEMM_SHAPES"):          # "M,N,K;M,N,K;..."
+    shapes = [tuple(int(v) for v in t.split(",")) for t in os.environ["DTF_GEMM_SHAPES"].split(";")]
 from distributed_tensorflow_amd.ops import hip as _hip
 _lib = _hip.lib()
 lin._lib()

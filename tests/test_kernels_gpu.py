@@ -853,3 +853,22 @@ def test_conv_wrw_matches_reference(dev, cfg, monkeypatch):
     m(x3).backward(dy)
     assert float((m.weight.grad.float() - ref).norm() / ref.norm()) < 1e-2
     assert float((x3.grad.float() - x2.grad).norm() / x2.grad.norm()) < 2e-2
+
+
+@pytest.mark.parametrize("n,rows,chunk", [(1, 10, 64), (1000, 50, 64), (5000, 3, 64), (70000, 100000, 64), (300001, 7, 64),
+                                          (4096, 1, 5), (2048, 2048 * 4, 64), (1025, 40, 3)])
+def test_segment_plan_kernel_matches_framework_ops(dev, n, rows, chunk):
+    """The plan kernels (run / chunk boundaries of the sorted ids) against the scatter_reduce formulation."""
+    from distributed_tensorflow_amd.ops import embedding as emb
+
+    torch.manual_seed(n)
+    idx = torch.randint(0, rows, (n,), device=dev)
+    if n > 3000:
+        idx[n // 3:n // 3 + 2500] = 1          # a run that crosses several 1024-position blocks
+    sid, perm, cb, sb, sfc, nc = emb.segment_plan(idx, chunk)
+    assert torch.equal(sid, idx[perm])
+    cb2, sb2, sfc2, nc2 = emb.segment_plan_reference(sid, chunk)
+    assert int(nc) == int(nc2)
+    assert torch.equal(cb, cb2)
+    assert torch.equal(sb, sb2)
+    assert torch.equal(sfc, sfc2)
