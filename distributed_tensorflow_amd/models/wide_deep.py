@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops.linear import fused_linear
 from ..parallel.comm import Comm
 from ..parallel.embedding import ShardedEmbedding
 
@@ -49,6 +50,19 @@ class WideDeep(nn.Module):
         e = self.embeddings(ids)                                   # [B, F, D + 8]
         deep = e[:, :, :self.embedding_dim].reshape(ids.shape[0], -1)
         wide = e[:, :, self.embedding_dim].float().sum(1, keepdim=True)
+        if deep.is_cuda and deep.dtype == torch.bfloat16:
+            # K6 / K6T path: bias + ReLU in the GEMM epilogue, dZ and the bias gradient in one pass.  The first
+            # layer's 26*64 + 13 = 1677 inputs are padded with zero columns to a whole number of 32-wide K
+            # tiles (the parameter keeps its TF shape; the pad of the 3 MB weight is a few microseconds).
+            pad = (-self.hidden[0].in_features) % 32
+            parts = [deep, dense.to(deep.dtype)]
+            if pad:
+                parts.append(deep.new_zeros(deep.shape[0], pad))
+            h = torch.cat(parts, 1)
+            for i, lin in enumerate(self.hidden):
+                w = F.pad(lin.weight, (0, pad)) if (i == 0 and pad) else lin.weight
+                h = fused_linear(h, w, lin.bias, act="relu")
+            return self.logits(h).float() + wide + self.wide_dense(dense.to(deep.dtype)).float()
         h = torch.cat([deep, dense.to(deep.dtype)], 1)
         for lin in self.hidden:
             h = F.relu(lin(h))
