@@ -26,6 +26,34 @@ NEEDS_COMM = True
 WIDE_PAD = 8
 
 
+class _SplitDeepWide(torch.autograd.Function):
+    """``e [B, F, D + pad]`` -> ``(deep [B, F*D], wide [B, 1] fp32)``: the deep-tower input and the summed wide
+    weights.  Autograd's version of the two slices materialises two zero-filled ``e``-sized gradients and adds
+    them (three extra passes over the largest activation of the model); here the gradient of ``e`` is written
+    once by a single concatenation."""
+
+    @staticmethod
+    def forward(ctx, e, D):
+        ctx.shape, ctx.D = e.shape, D
+        deep = e[:, :, :D].reshape(e.shape[0], -1)
+        wide = e[:, :, D].float().sum(1, keepdim=True)
+        return deep, wide
+
+    @staticmethod
+    def backward(ctx, d_deep, d_wide):
+        B, F_, W = ctx.shape
+        D = ctx.D
+        dt = d_deep.dtype if d_deep is not None else d_wide.dtype
+        dev = d_deep.device if d_deep is not None else d_wide.device
+        gd = d_deep.reshape(B, F_, D) if d_deep is not None else torch.zeros(B, F_, D, dtype=dt, device=dev)
+        gw = (d_wide.to(dt).unsqueeze(1).expand(B, F_, 1) if d_wide is not None
+              else torch.zeros(B, F_, 1, dtype=dt, device=dev))
+        parts = [gd, gw]
+        if W - D - 1 > 0:
+            parts.append(torch.zeros(B, F_, W - D - 1, dtype=dt, device=dev))
+        return torch.cat(parts, 2), None
+
+
 class WideDeep(nn.Module):
     def __init__(self, comm=None, device=None, num_features=26, rows_per_table=100000, embedding_dim=64,
                  dense_features=13, hidden=(1024, 512, 256), emb_optimizer="adagrad", emb_lr=0.05, atomic=False):
@@ -48,8 +76,7 @@ class WideDeep(nn.Module):
 
     def forward(self, ids, dense):
         e = self.embeddings(ids)                                   # [B, F, D + 8]
-        deep = e[:, :, :self.embedding_dim].reshape(ids.shape[0], -1)
-        wide = e[:, :, self.embedding_dim].float().sum(1, keepdim=True)
+        deep, wide = _SplitDeepWide.apply(e, self.embedding_dim)
         if deep.is_cuda and deep.dtype == torch.bfloat16:
             # K6 / K6T path: bias + ReLU in the GEMM epilogue, dZ and the bias gradient in one pass.  The first
             # layer's 26*64 + 13 = 1677 inputs are padded with zero columns to a whole number of 32-wide K
