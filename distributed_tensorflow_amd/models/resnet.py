@@ -58,9 +58,18 @@ class Bottleneck(nn.Module):
             y, x = self.conv1.forward_fork(x, own_skip_grad=True)
         else:
             y = self.conv1(x)
-        sc = x if self.shortcut_conv is None else self.shortcut_bn(self.shortcut_conv(x))
+        if self.shortcut_conv is None:
+            sc = x
+        elif isinstance(self.shortcut_conv, Conv1x1):
+            s, st = self.shortcut_conv.forward_stats(x)      # BN statistics from the GEMM epilogue (K6 STATS)
+            sc = self.shortcut_bn(s, stats=st)
+        else:
+            sc = self.shortcut_bn(self.shortcut_conv(x))
         y = self.bn1(y)
         y = self.bn2(self.conv2(y))
+        if isinstance(self.conv3, Conv1x1):
+            y, st = self.conv3.forward_stats(y)
+            return self.bn3(y, sc, stats=st)
         return self.bn3(self.conv3(y), sc)
 
 

@@ -29,6 +29,7 @@ def _lib():
         hip.declare("dtf_bn_partial_floats", [L, I], L)
         hip.declare("dtf_bn_mask_bytes", [L, I], L)
         hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, L, P])
+        hip.declare("dtf_bn_fwd_train_pre", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, I, L, I, I, L, P])
         hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, P, L, I, I, P])
         hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, P])
         _declared = True
@@ -68,7 +69,9 @@ def kernel_eligible(x, weight):
 
 class _FusedBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, pre=None):
+        # pre: fp32 [nblk, 2, C] column sums / sums of squares of x from its producer (K6 STATS epilogue,
+        # ops/conv.py conv1x1_stats) -- the statistics pass over x is skipped
         lib = _lib()
         M, C = _nhwc_rows(x)
         dev = x.device
@@ -79,11 +82,19 @@ class _FusedBNAct(torch.autograd.Function):
             assert residual.shape == x.shape and residual.dtype == x.dtype and _nhwc_rows(residual) is not None
             if relu:
                 mask = torch.empty(int(lib.dtf_bn_mask_bytes(M, C)), dtype=torch.uint8, device=dev)
-        rc = lib.dtf_bn_fwd_train(
-            hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
-            hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
-            stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-            hip.ptr(_partial(dev, M, C)), M, C, int(relu), 0, hip.stream())
+        if pre is not None:
+            assert pre.dtype == torch.float32 and pre.dim() == 3 and pre.shape[1] == 2 and pre.shape[2] == C and pre.is_contiguous()
+            rc = lib.dtf_bn_fwd_train_pre(
+                hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
+                hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
+                stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                hip.ptr(pre), int(pre.shape[0]), M, C, int(relu), 0, hip.stream())
+        else:
+            rc = lib.dtf_bn_fwd_train(
+                hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
+                hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
+                stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                hip.ptr(_partial(dev, M, C)), M, C, int(relu), 0, hip.stream())
         hip.check(rc, "dtf_bn_fwd_train")
         ctx.save_for_backward(x, mask, weight, stats)
         # ReLU mask source for backward: 1 = recompute from x (no residual), 3 = bit mask
@@ -109,7 +120,7 @@ class _FusedBNAct(torch.autograd.Function):
             dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
             int(ctx.relu_mode), 0, hip.stream())
         hip.check(rc, "dtf_bn_bwd_train")
-        return dx, dgb[0], dgb[1], dres, None, None, None, None, None
+        return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None
 
 
 class _BNConcat(torch.autograd.Function):
@@ -206,8 +217,9 @@ def bn_act_reference(x, weight, bias, residual, running_mean, running_var, train
 
 
 def fused_bn_act(x, weight, bias, residual=None, running_mean=None, running_var=None, training=True,
-                 momentum=0.1, eps=1e-5, relu=True):
-    """``[relu]( batch_norm(x) [+ residual] )``."""
+                 momentum=0.1, eps=1e-5, relu=True, stats=None):
+    """``[relu]( batch_norm(x) [+ residual] )``.  ``stats``: statistics partials of ``x`` from its producer
+    (see ``_FusedBNAct``), used in training mode on the kernel path only."""
     if not kernel_eligible(x, weight):
         if x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and \
                 not x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0:
@@ -220,7 +232,7 @@ def fused_bn_act(x, weight, bias, residual=None, running_mean=None, running_var=
                 w, b = weight.to(x.dtype), bias.to(x.dtype)
             return bn_act_reference(x, w, b, residual, running_mean, running_var, training, momentum, eps, relu)
     if training:
-        return _FusedBNAct.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu)
+        return _FusedBNAct.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats)
     # inference: statistics are constants -> a single fused apply pass
     lib = _lib()
     M, C = _nhwc_rows(x)
@@ -258,7 +270,7 @@ class FusedBatchNormAct(nn.Module):
                 setattr(self, name, new.float())
         return self
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, stats=None):
         rm, rv = self.running_mean, self.running_var
         if not x.is_cuda and x.dtype != torch.float32:
             rm, rv = rm.to(x.dtype), rv.to(x.dtype)
@@ -269,7 +281,7 @@ class FusedBatchNormAct(nn.Module):
                 self.running_var.copy_(rv)
             return y
         return fused_bn_act(x, self.weight, self.bias, residual, rm, rv, self.training, self.momentum,
-                            self.eps, self.relu)
+                            self.eps, self.relu, stats)
 
     def extra_repr(self):
         return "%d, relu=%s, eps=%g, momentum=%g" % (self.num_features, self.relu, self.eps, self.momentum)

@@ -79,6 +79,59 @@ class _Conv1x1Fn(torch.autograd.Function):
         return dx, dw
 
 
+# BatchNorm statistics in the K6 GEMM epilogue.  Off by default: measured on ResNet-50 batch 256
+# (scripts/conv1x1_stats_bench.py) the saved statistics pass (30-56 us per expand layer) is eaten by K6 being
+# 15-50 us slower than MIOpen's kernels on these memory-bound shapes (9 650 vs 9 680 images/s end to end).
+_STATS = os.environ.get("DTF_CONV1X1_STATS", "0") != "0"
+_STATS_MIN_COUT = 256
+_stats_declared = False
+
+
+class _Conv1x1StatsFn(torch.autograd.Function):
+    """1x1 convolution on K6 whose epilogue also reduces the output over the pixels: ``(y, partials)`` with
+    ``partials`` = fp32 ``[2 * ceil(M / 256), 2, Cout]`` column sums / sums of squares, which the following
+    training-mode BatchNorm (``FusedBatchNormAct(..., stats=partials)``) finalizes instead of reading ``y`` once
+    more -- the statistics pass is 2 B/element of pure HBM traffic on the widest activations of a ResNet."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        global _stats_declared
+        import ctypes
+
+        from . import hip
+
+        lib = hip.lib()
+        if not _stats_declared:
+            P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+            hip.declare("dtf_gemm_stats_blocks", [L], L)
+            hip.declare("dtf_gemm_stats", [P, P, P, P, I, I, I, P])
+            _stats_declared = True
+        ctx.save_for_backward(x, weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        N, _, H, W = x.shape
+        x2 = _rows(x)
+        M = x2.shape[0]
+        y2 = torch.empty(M, cout, dtype=x.dtype, device=x.device)
+        part = torch.empty(int(lib.dtf_gemm_stats_blocks(M)), 2, cout, dtype=torch.float32, device=x.device)
+        rc = lib.dtf_gemm_stats(hip.ptr(x2), hip.ptr(weight), hip.ptr(y2), hip.ptr(part), M, cout, cin, hip.stream())
+        hip.check(rc, "dtf_gemm_stats")
+        ctx.mark_non_differentiable(part)
+        return y2.view(N, H, W, cout).permute(0, 3, 1, 2), part
+
+    @staticmethod
+    def backward(ctx, dy, _dpart):
+        return _Conv1x1Fn.backward(ctx, dy)
+
+
+def conv1x1_stats(x, weight):
+    """-> ``(conv1x1(x, weight), partials or None)``; see :class:`_Conv1x1StatsFn`."""
+    if (_STATS and _eligible(x, weight) and weight.dtype == torch.bfloat16 and weight.shape[0] >= _STATS_MIN_COUT
+            and weight.shape[0] % 8 == 0 and weight.shape[1] % 32 == 0 and weight.is_contiguous(memory_format=torch.channels_last)
+            and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 31) - 256):
+        return _Conv1x1StatsFn.apply(x, weight)
+    return conv1x1(x, weight), None
+
+
 class _Conv1x1ForkFn(torch.autograd.Function):
     """``(conv1x1(x, w), x)``: the convolution plus a pass-through of its input for a second consumer
     (the residual shortcut).  Autograd would sum the two gradients of ``x`` with a separate elementwise
@@ -161,6 +214,10 @@ class Conv1x1(nn.Conv2d):
 
     def forward_fork(self, x, own_skip_grad=False):
         return conv1x1_fork(x, self.weight, own_skip_grad)
+
+    def forward_stats(self, x):
+        """-> ``(self(x), stats)`` for a following ``FusedBatchNormAct(y, ..., stats=stats)``."""
+        return conv1x1_stats(x, self.weight)
 
 
 # ---------------------------------------------------------------------------

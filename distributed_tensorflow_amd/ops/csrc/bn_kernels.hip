@@ -441,6 +441,33 @@ int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const 
     return 0;
 }
 
+// Training forward with the statistics partials already computed by the producer of x (K6 STATS epilogue):
+// partial = fp32 [nblk][2][C] column sums / sums of squares; finalize + apply only.
+int dtf_bn_fwd_train_pre(const void* x, const void* res, void* y, void* mask, const void* gamma, const void* beta,
+                         int param_dtype, float* running_mean, float* running_var, float momentum, float eps,
+                         float* mean, float* invstd, float* scale, float* shift, const float* partial, int nblk,
+                         int64_t M, int C, int relu, int64_t ldy, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0 || nblk <= 0) return -20;
+    if (ldy == 0) ldy = C;
+    if (ldy < C || (ldy & 7)) return -24;
+    if (relu && res && !mask) return -22;
+    const float inv_count = 1.0f / (float)M;
+    const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
+    if (param_dtype == DTF_BF16)
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C,
+                           inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                           scale, shift);
+    else
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C,
+                           inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                           scale, shift);
+    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, ldy, stream);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
 // Inference / frozen-statistics forward: scale/shift precomputed by the caller.
 int dtf_bn_fwd_apply(const void* x, const void* res, void* y, void* mask, const float* scale, const float* shift,
                      int64_t M, int C, int relu, hipStream_t stream) {

@@ -70,6 +70,7 @@ struct GemmArgs {
     const unsigned short* X; const unsigned short* W; const void* bias; const unsigned short* residual;
     unsigned short* Y; unsigned short* preact;
     int M, N, K; int bias_dtype; int act; int ntm, ntn;
+    float* stats;        // gemm256p_kernel<.., STATS = true>: per-row-block column sums / sums of squares of Y
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -257,7 +258,20 @@ __device__ __forceinline__ float k6_act(float x, int act) {
     return x;
 }
 
-template <int ACT>
+// sum over the 16 lanes of a DPP row (lane & 15): row_ror 8, row_ror 4, then the two quad permutes
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    return v;
+}
+
+// STATS: the epilogue also reduces the (bf16-rounded) output tile over its rows -- per 128-row half tile the
+// column sums and sums of squares, written as partial rows [(2 tm + wr) * 2 + stat][N] in the layout the K7
+// BatchNorm finalize kernel reads: a 1x1 convolution feeding a training-mode BatchNorm needs no separate
+// statistics pass over its output (2 B/element of HBM reads saved).
+template <int ACT, bool STATS = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -410,7 +424,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
         // inline asm so that the compiler does not drain the in-flight LDS-DMA of the next tile first.
         if ((a.N & 7) == 0) {
             const unsigned ebase = (unsigned)(uintptr_t)(lds_void_t*)smem + 98304u + (unsigned)wave * 4096u;
-            const int rrow = lane >> 2, rq = lane & 3;          // read-back: row, 16-column group
+            const int rr = lane >> 3, rc = lane & 7;            // read-back: row (and row + 8), 8-column group
+            float st1[4][4], st2[4][4];
+            if (STATS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { st1[j][r] = 0.f; st2[j][r] = 0.f; }
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int m = cm0 + wr * 128 + i * 16 + frow;
@@ -420,6 +441,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
                     f32x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
+                    if (STATS && m < a.M) {          // statistics of what the consumer will read: the rounded values
+                        const unsigned p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+                        const float q[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u),
+                                            __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { st1[j][r] += q[r]; st2[j][r] = fmaf(q[r], q[r], st2[j][r]); }
+                    }
                     if (a.preact && m < a.M && n < a.N) {
                         u32x2 pk;
                         pk[0] = pack_bf16x2(v[0], v[1]);
@@ -432,35 +460,49 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
                     asm volatile("ds_write_b128 %0, %1" ::"v"(wa), "v"(v) : "memory");
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // read-back: lane = (row rr [+8], column octet rc): 8 lanes x 16 B cover one 128-B output line, so
+                // every store instruction writes whole lines (4 lanes x 2 half-filled 32-B sectors per row measured
+                // 2.5 TB/s of stores on the memory-bound 1x1-convolution shapes)
                 f32x4 o4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const unsigned ra = ebase + (unsigned)(rrow * 256 + (((rq * 4 + q) ^ rrow) << 4));
+                    const int row = rr + 8 * (q >> 1);
+                    const unsigned ra = ebase + (unsigned)(row * 256 + (((rc * 2 + (q & 1)) ^ row) << 4));
                     asm volatile("ds_read_b128 %0, %1" : "=v"(o4[q]) : "v"(ra) : "memory");
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                const int om = cm0 + wr * 128 + i * 16 + rrow;
-                const int on = cn0 + wc * 64 + rq * 16;
-                if (om < a.M && on < a.N) {
-                    const int64_t o = (int64_t)om * a.N + on;
-                    float lo[8], hi[8];
+                const int on = cn0 + wc * 64 + rc * 8;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { lo[k] = o4[0][k]; lo[4 + k] = o4[1][k]; hi[k] = o4[2][k]; hi[4 + k] = o4[3][k]; }
-                    const bool two = on + 8 < a.N;          // N % 8 == 0: the second octet is all-or-nothing
-                    if (a.residual) {
-                        float r8[8];
-                        load8<DTF_BF16>(a.residual, o, r8);
+                for (int h = 0; h < 2; ++h) {
+                    const int om = cm0 + wr * 128 + i * 16 + rr + 8 * h;
+                    if (om < a.M && on < a.N) {          // N % 8 == 0: an octet is all-or-nothing
+                        const int64_t o = (int64_t)om * a.N + on;
+                        float v8[8];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) lo[k] += r8[k];
-                        if (two) {
-                            load8<DTF_BF16>(a.residual, o + 8, r8);
+                        for (int k = 0; k < 4; ++k) { v8[k] = o4[2 * h][k]; v8[4 + k] = o4[2 * h + 1][k]; }
+                        if (a.residual) {
+                            float r8[8];
+                            load8<DTF_BF16>(a.residual, o, r8);
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) hi[k] += r8[k];
+                            for (int k = 0; k < 8; ++k) v8[k] += r8[k];
                         }
+                        store8<DTF_BF16>(a.Y, o, v8);
                     }
-                    store8<DTF_BF16>(a.Y, o, lo);
-                    if (two) store8<DTF_BF16>(a.Y, o + 8, hi);
+                }
+            }
+            if (STATS) {
+                const int blk = (cm0 / G2_BM) * 2 + wr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 o1, o2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { o1[r] = row16_sum(st1[j][r]); o2[r] = row16_sum(st2[j][r]); }
+                    const int n = cn0 + wc * 64 + j * 16 + fq * 4;
+                    if (frow == 0 && n < a.N) {
+                        *reinterpret_cast<f32x4*>(a.stats + ((int64_t)blk * 2 + 0) * a.N + n) = o1;
+                        *reinterpret_cast<f32x4*>(a.stats + ((int64_t)blk * 2 + 1) * a.N + n) = o2;
+                    }
                 }
             }
         } else {
@@ -581,7 +623,7 @@ int dtf_gemm_bias_act(const void* X, const void* W, const void* bias, int bias_d
     if ((((uintptr_t)X) | ((uintptr_t)W) | ((uintptr_t)Y) | ((uintptr_t)residual) | ((uintptr_t)preact)) & 15) return -16;
     GemmArgs a{(const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)residual,
                (unsigned short*)Y, (unsigned short*)preact, M, N, K, bias_dtype, act,
-               (M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN};
+               (M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN, nullptr};
     static bool attr_set = false;
     const int lds = GM_BM * (GM_BN + 4) * 4;     // 67584 B: epilogue tile (>= 64 KB staging)
     const int lds256 = 131072;                   // four 32 KB K-tile buffers
@@ -615,6 +657,34 @@ int dtf_gemm_bias_act(const void* X, const void* W, const void* bias, int bias_d
     } else {
         hipLaunchKernelGGL(gemm_bias_act_kernel, dim3(a.ntm * a.ntn), dim3(256), lds, stream, a);
     }
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// partial rows of dtf_gemm_stats: two 128-row halves per 256-row tile
+int64_t dtf_gemm_stats_blocks(int64_t M) { return 2 * ((M + G2_BM - 1) / G2_BM); }
+
+// Y[M,N] = X[M,K] . W[N,K]^T (bf16) plus the BatchNorm statistics partials of Y (see gemm256p_kernel STATS):
+// stats: fp32 [dtf_gemm_stats_blocks(M)][2][N]
+int dtf_gemm_stats(const void* X, const void* W, void* Y, float* stats, int M, int N, int K, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K & 31) || (N & 7)) return -42;
+    if ((((uintptr_t)X) | ((uintptr_t)W) | ((uintptr_t)Y) | ((uintptr_t)stats)) & 15) return -16;
+    GemmArgs a{(const unsigned short*)X, (const unsigned short*)W, nullptr, nullptr, (unsigned short*)Y, nullptr, M, N, K, 0,
+               ACT_NONE, (M + G2_BM - 1) / G2_BM, (N + G2_BN - 1) / G2_BN, stats};
+    static bool attr_set = false;
+    static int num_cu = 0;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0) num_cu = 256;
+        attr_set = true;
+    }
+    const int ntiles = a.ntm * a.ntn;
+    hipLaunchKernelGGL((gemm256p_kernel<ACT_NONE, true>), dim3(ntiles < num_cu ? ntiles : num_cu), dim3(512), 131072, stream, a,
+                       ntiles);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -872,3 +872,46 @@ def test_segment_plan_kernel_matches_framework_ops(dev, n, rows, chunk):
     assert torch.equal(cb, cb2)
     assert torch.equal(sb, sb2)
     assert torch.equal(sfc, sfc2)
+
+
+@pytest.mark.parametrize("shape,cout", [((8, 64, 28, 28), 256), ((3, 128, 15, 13), 512), ((2, 256, 14, 14), 1024), ((5, 512, 7, 7), 2048),
+                                       ((1, 32, 9, 9), 264)])
+def test_conv1x1_stats_epilogue_feeds_batchnorm(dev, shape, cout, monkeypatch):
+    """1x1 convolution on K6 with the BatchNorm statistics reduced in the GEMM epilogue: output, partial sums and the
+    BN layer fed with them against the two-kernel path (conv, then BN with its own statistics pass)."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, conv
+
+    torch.manual_seed(0)
+    N, cin, H, W = shape
+    x = torch.randn(N, cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(N, cout, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(N, cout, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    monkeypatch.setattr(conv, "_STATS", True)
+    y, part = conv.conv1x1_stats(x, w)
+    assert part is not None and part.shape[1:] == (2, cout)
+    ref = torch.nn.functional.conv2d(x.float(), w.float())
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+    yf = y.float()
+    s1, s2 = part[:, 0].sum(0), part[:, 1].sum(0)
+    torch.testing.assert_close(s1, yf.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(s2, (yf * yf).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    outs = []
+    for use in (True, False):
+        monkeypatch.setattr(conv, "_STATS", use)
+        bn = bnmod.FusedBatchNormAct(cout, relu=True).to(dev).to(torch.bfloat16).train()
+        torch.manual_seed(1)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.5, 0.5)
+        x1, w1 = x.clone().requires_grad_(), w.clone().requires_grad_()
+        yy, st = conv.conv1x1_stats(x1, w1)
+        assert (st is not None) == use
+        out = bn(yy, res, stats=st)
+        out.backward(dy)
+        outs.append((out.detach().float(), x1.grad.float(), w1.grad.float(), bn.weight.grad.float(), bn.running_var.clone()))
+    a, b = outs
+    torch.testing.assert_close(a[0], b[0], rtol=3e-2, atol=3e-2)
+    for i in (1, 2, 3):
+        assert float((a[i] - b[i]).norm() / (b[i].norm() + 1e-6)) < 4e-2, i      # bf16 outputs of two GEMM kernels, ReLU knife edges
+    torch.testing.assert_close(a[4], b[4], rtol=1e-2, atol=5e-3)      # y comes from two different GEMM kernels
