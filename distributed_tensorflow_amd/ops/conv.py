@@ -298,8 +298,38 @@ def conv_wrw(dy, x, weight, stride, padding):
     return dw.permute(0, 3, 1, 2)
 
 
+# Data gradient of a stride-1 convolution as a FORWARD convolution of dY with the spatially flipped, channel-
+# transposed filter (padding K-1-p).  MIOpen's tuned forward kernels run at 500-830 TFLOP/s on the 3x3 / 1x7 / 7x1
+# shapes of ResNet and Inception, its backward-data kernels at 300-490 (scripts/conv_wrw_bench.py with
+# DTF_BENCH_FWD_DGRAD=1); the filter transform is two small copies of a <= 5 MB tensor.
+# "same": only where the transposed problem IS the layer's own forward problem (Cin == Cout, 'same' padding), so
+# the shipped tuning covers it; "all": every stride-1 layer (needs the transposed shapes in the tuning DB); "0": off.
+_DGRAD_AS_FWD = os.environ.get("DTF_CONV_DGRAD_FWD", "same")
+
+
+def _dgrad_as_fwd_ok(x, weight, stride, padding):
+    if _DGRAD_AS_FWD == "0" or stride[0] != 1 or stride[1] != 1:
+        return False
+    kh, kw = weight.shape[2], weight.shape[3]
+    if kh == 1 and kw == 1:
+        return False
+    if padding[0] > kh - 1 or padding[1] > kw - 1:
+        return False
+    if _DGRAD_AS_FWD == "all":
+        return True
+    return weight.shape[0] == weight.shape[1] and 2 * padding[0] == kh - 1 and 2 * padding[1] == kw - 1
+
+
+def dgrad_as_forward(dy, weight, padding):
+    """``dX`` of a stride-1, dilation-1 ``conv2d(x, weight, padding=padding)``."""
+    kh, kw = weight.shape[2], weight.shape[3]
+    wt = weight.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    return F.conv2d(dy, wt, None, 1, (kh - 1 - padding[0], kw - 1 - padding[1]))
+
+
 class _ConvFn(torch.autograd.Function):
-    """``conv2d`` whose weight gradient runs on K6T (MIOpen keeps forward and the data gradient)."""
+    """``conv2d`` with per-product kernel choice in backward: weight gradient on K6T where that wins, data gradient
+    as a forward convolution where that wins, MIOpen's backward kernels otherwise."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, padding):
@@ -314,23 +344,28 @@ class _ConvFn(torch.autograd.Function):
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
-        use_tn = (ctx.needs_input_grad[1] and conv_wrw_profitable(weight)
+        use_tn = (ctx.needs_input_grad[1] and _CONV_WRW and conv_wrw_profitable(weight)
                   and conv_wrw_eligible(dy, x, weight, stride, padding))
-        mask = [ctx.needs_input_grad[0], ctx.needs_input_grad[1] and not use_tn, False]
+        use_fwd = ctx.needs_input_grad[0] and _dgrad_as_fwd_ok(x, weight, stride, padding)
+        mask = [ctx.needs_input_grad[0] and not use_fwd, ctx.needs_input_grad[1] and not use_tn, False]
         if mask[0] or mask[1]:
             gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, list(stride), list(padding), [1, 1], False,
                                                             [0, 0], 1, mask)
             dx, dw = (gx if mask[0] else None), (gw if mask[1] else None)
+        if use_fwd:
+            dx = dgrad_as_forward(dy, weight, padding)
         if use_tn:
             dw = conv_wrw(dy, x, weight, stride, padding)
         return dx, dw, None, None
 
 
 class Conv2dTN(nn.Conv2d):
-    """``nn.Conv2d`` (bias-free, groups 1) with the K6T weight gradient where it is eligible."""
+    """``nn.Conv2d`` (bias-free, groups 1) whose backward picks the kernel per product (see :class:`_ConvFn`)."""
 
     def forward(self, x):
         if (self.bias is None and self.groups == 1 and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
-                and _CONV_WRW and isinstance(self.padding, tuple) and conv_wrw_profitable(self.weight)):
+                and isinstance(self.padding, tuple) and self.dilation == (1, 1)
+                and ((_CONV_WRW and conv_wrw_profitable(self.weight))
+                     or _dgrad_as_fwd_ok(x, self.weight, self.stride, self.padding))):
             return _ConvFn.apply(x, self.weight, self.stride, self.padding)
         return super().forward(x)

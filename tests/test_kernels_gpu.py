@@ -915,3 +915,27 @@ def test_conv1x1_stats_epilogue_feeds_batchnorm(dev, shape, cout, monkeypatch):
     for i in (1, 2, 3):
         assert float((a[i] - b[i]).norm() / (b[i].norm() + 1e-6)) < 4e-2, i      # bf16 outputs of two GEMM kernels, ReLU knife edges
     torch.testing.assert_close(a[4], b[4], rtol=1e-2, atol=5e-3)      # y comes from two different GEMM kernels
+
+
+@pytest.mark.parametrize("cfg", [(4, 64, 14, 14, 64, 3, 3, (1, 1)), (2, 160, 17, 17, 192, 7, 1, (3, 0)), (2, 192, 17, 17, 160, 1, 7, (0, 3)),
+                                 (3, 48, 12, 12, 64, 5, 5, (2, 2)), (2, 32, 9, 9, 48, 3, 3, (0, 0))])
+def test_conv_data_gradient_as_forward_convolution(dev, cfg, monkeypatch):
+    from distributed_tensorflow_amd.ops import conv
+
+    NB, Cin, H, W, Cout, KH, KW, pad = cfg
+    torch.manual_seed(0)
+    x = torch.randn(NB, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    m = conv.Conv2dTN(Cin, Cout, (KH, KW), padding=pad, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x2, w2 = x.float().requires_grad_(), m.weight.detach().float().requires_grad_()
+    y2 = torch.nn.functional.conv2d(x2, w2, None, 1, pad)
+    dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y2.backward(dy.float())
+    monkeypatch.setattr(conv, "_DGRAD_AS_FWD", "all")
+    assert conv._dgrad_as_fwd_ok(x, m.weight, (1, 1), pad)
+    x1 = x.clone().requires_grad_()
+    y1 = m(x1)
+    assert y1.grad_fn is not None and "ConvFn" in type(y1.grad_fn).__name__
+    y1.backward(dy)
+    assert x1.grad.shape == x.shape
+    assert float((x1.grad.float() - x2.grad).norm() / x2.grad.norm()) < 1e-2
+    assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
