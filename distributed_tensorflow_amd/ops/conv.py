@@ -302,9 +302,11 @@ def conv_wrw(dy, x, weight, stride, padding):
 # transposed filter (padding K-1-p).  MIOpen's tuned forward kernels run at 500-830 TFLOP/s on the 3x3 / 1x7 / 7x1
 # shapes of ResNet and Inception, its backward-data kernels at 300-490 (scripts/conv_wrw_bench.py with
 # DTF_BENCH_FWD_DGRAD=1); the filter transform is two small copies of a <= 5 MB tensor.
-# "same": only where the transposed problem IS the layer's own forward problem (Cin == Cout, 'same' padding), so
-# the shipped tuning covers it; "all": every stride-1 layer (needs the transposed shapes in the tuning DB); "0": off.
-_DGRAD_AS_FWD = os.environ.get("DTF_CONV_DGRAD_FWD", "same")
+# "all" (default): every stride-1 KxK layer -- the transposed forward problems of the shipped models are in the
+# shipped tuning DB (Inception-v3 batch 256: 6 794 -> 6 920 images/s over "same"; untuned they LOSE: 6 320);
+# "same": only where the transposed problem IS the layer's own forward problem (Cin == Cout, 'same' padding);
+# "0": off.
+_DGRAD_AS_FWD = os.environ.get("DTF_CONV_DGRAD_FWD", "all")
 
 
 def _dgrad_as_fwd_ok(x, weight, stride, padding):
