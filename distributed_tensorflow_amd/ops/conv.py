@@ -309,6 +309,10 @@ def conv_wrw(dy, x, weight, stride, padding):
 _DGRAD_AS_FWD = os.environ.get("DTF_CONV_DGRAD_FWD", "all")
 
 
+_ft_declared = False
+_FT_KERNEL = os.environ.get("DTF_FILTER_KERNEL", "1") != "0"      # A/B switch: 0 = framework flip + copy
+
+
 def _dgrad_as_fwd_ok(x, weight, stride, padding):
     if _DGRAD_AS_FWD == "0" or stride[0] != 1 or stride[1] != 1:
         return False
@@ -324,8 +328,25 @@ def _dgrad_as_fwd_ok(x, weight, stride, padding):
 
 def dgrad_as_forward(dy, weight, padding):
     """``dX`` of a stride-1, dilation-1 ``conv2d(x, weight, padding=padding)``."""
-    kh, kw = weight.shape[2], weight.shape[3]
-    wt = weight.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    cout, cin, kh, kw = weight.shape
+    if (_FT_KERNEL and weight.is_cuda and weight.dtype == torch.bfloat16
+            and weight.is_contiguous(memory_format=torch.channels_last)):
+        global _ft_declared
+        import ctypes
+
+        from . import hip
+
+        lib = hip.lib()
+        if not _ft_declared:
+            hip.declare("dtf_filter_flip_transpose", [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_void_p])
+            _ft_declared = True
+        buf = torch.empty((cin, kh, kw, cout), dtype=weight.dtype, device=weight.device)
+        hip.check(lib.dtf_filter_flip_transpose(hip.ptr(weight), hip.ptr(buf), cout, cin, kh * kw, hip.stream()),
+                  "dtf_filter_flip_transpose")
+        wt = buf.permute(0, 3, 1, 2)          # [Cin, Cout, KH, KW], channels_last-dense
+    else:
+        wt = weight.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
     return F.conv2d(dy, wt, None, 1, (kh - 1 - padding[0], kw - 1 - padding[1]))
 
 

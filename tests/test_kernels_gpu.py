@@ -939,3 +939,18 @@ def test_conv_data_gradient_as_forward_convolution(dev, cfg, monkeypatch):
     assert x1.grad.shape == x.shape
     assert float((x1.grad.float() - x2.grad).norm() / x2.grad.norm()) < 1e-2
     assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (192, 160, 7, 1), (96, 48, 5, 5), (384, 448, 3, 3), (72, 8, 1, 7)])
+def test_filter_flip_transpose_kernel(dev, shape):
+    from distributed_tensorflow_amd.ops import conv
+
+    cout, cin, kh, kw = shape
+    torch.manual_seed(0)
+    w = torch.randn(cout, cin, kh, kw, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(2, cout, 9, 9, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    pad = ((kh - 1) // 2, (kw - 1) // 2)
+    got = conv.dgrad_as_forward(dy, w, pad)
+    wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+    ref = torch.nn.functional.conv2d(dy, wt, None, 1, (kh - 1 - pad[0], kw - 1 - pad[1]))
+    assert torch.equal(got, ref)
