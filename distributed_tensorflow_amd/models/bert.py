@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 from ..ops import attention
 from ..ops.layernorm import FusedLayerNorm
+from ..ops.cross_entropy import cross_entropy
 from ..ops.linear import FusedLinear
 
 
@@ -176,8 +177,15 @@ def synthetic_batch(batch, device="cpu", seed=None, seq_len=512, vocab=30522, ma
 
 def loss_fn(model, batch):
     ids, types, mask, pos, labels, nsp = batch
-    mlm_logits, nsp_logits = model(ids, types, None if bool((mask == 1).all()) else mask, pos)
-    return F.cross_entropy(mlm_logits.float(), labels.reshape(-1)) + F.cross_entropy(nsp_logits.float(), nsp)
+    # "no padding" is decided once per mask tensor: the check reads a device value (a host sync), which per
+    # step would drain the launch queue
+    full = getattr(mask, "_dtf_all_ones", None)
+    if full is None:
+        full = bool((mask == 1).all())
+        mask._dtf_all_ones = full
+    mlm_logits, nsp_logits = model(ids, types, None if full else mask, pos)
+    # K12: the [B*76, 30522] MLM logits stay bf16 in memory, softmax arithmetic in fp32 registers
+    return cross_entropy(mlm_logits, labels.reshape(-1)) + F.cross_entropy(nsp_logits.float(), nsp)
 
 
 def default_optimizer():

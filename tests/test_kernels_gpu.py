@@ -954,3 +954,33 @@ def test_filter_flip_transpose_kernel(dev, shape):
     wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
     ref = torch.nn.functional.conv2d(dy, wt, None, 1, (kh - 1 - pad[0], kw - 1 - pad[1]))
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("M,V", [(64, 30522), (37, 1000), (5, 7), (300, 4096), (16, 30523)])
+def test_cross_entropy_kernel_matches_reference(dev, M, V):
+    from distributed_tensorflow_amd.ops import cross_entropy as ce
+
+    torch.manual_seed(0)
+    base = torch.empty(M * V + 8, device=dev, dtype=torch.bfloat16)
+    logits = base[:M * V].view(M, V)
+    logits.copy_(torch.randn(M, V, device=dev) * 3)
+    labels = torch.randint(0, V, (M,), device=dev)
+    if M > 4:
+        labels[1] = -100                      # ignored row
+    assert ce.kernel_eligible(logits, labels)
+    l1 = logits.clone().requires_grad_()
+    loss = ce.cross_entropy(l1, labels)
+    loss.backward()
+    l2 = logits.float().requires_grad_()
+    ref = torch.nn.functional.cross_entropy(l2, labels)
+    ref.backward()
+    assert loss.dtype == torch.float32
+    torch.testing.assert_close(loss, ref, rtol=1e-4, atol=1e-4)
+    assert l1.grad.dtype == torch.bfloat16
+    torch.testing.assert_close(l1.grad.float(), l2.grad, rtol=1e-2, atol=1e-6)
+    if M > 4:
+        assert float(l1.grad[1].abs().max()) == 0.0
+    # scaled upstream gradient
+    l3 = logits.clone().requires_grad_()
+    (ce.cross_entropy(l3, labels) * 2.5).backward()
+    torch.testing.assert_close(l3.grad.float(), l2.grad * 2.5, rtol=1e-2, atol=1e-6)
