@@ -271,7 +271,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // column sums and sums of squares, written as partial rows [(2 tm + wr) * 2 + stat][N] in the layout the K7
 // BatchNorm finalize kernel reads: a 1x1 convolution feeding a training-mode BatchNorm needs no separate
 // statistics pass over its output (2 B/element of HBM reads saved).
-template <int ACT, bool STATS = false>
+// NJ: 16-column B fragments per wave -- the tile is 256 x (64 * NJ): NJ = 3 (256 x 192) where that fills the CUs in
+// fewer tile-rounds (N = 768: 384 tiles of 256^2 are 1.5 rounds on 256 CUs, 512 tiles of 256 x 192 are exactly 2).
+template <int ACT, bool STATS = false, int NJ = 4>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
     auto set_tile = [&](int tile) {        // wave w stages row groups 2w, 2w+1 of A and of B
         const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
         m0 = tm * G2_BM;
-        n0 = tn * G2_BN;
+        n0 = tn * (64 * NJ);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             // LDS-DMA lane l lands at byte 16 l of the 1 KB piece = [16 rows][4 chunks of 16 B] with 4
@@ -340,11 +342,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
     }
     for (; tile < ntiles; tile += gridDim.x) {
         const int cm0 = m0, cn0 = n0;
-        f32x4 acc[8][4];
+        f32x4 acc[8][NJ];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // the prefetched K tiles (and the previous epilogue's stores) have landed.  This wait must be the
         // BUILTIN (a real S_WAITCNT the compiler's wait-count pass sees, vmcnt(0) = 0x0F70 on gfx9): with an
         // asm string it still believes the epilogue's stores are pending at the K loop and drains
@@ -354,10 +356,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
         if (wr == 1) __builtin_amdgcn_s_barrier();          // stagger the second wave of every SIMD
         for (int t = 0; t < nk; ++t) {
             const unsigned char* A = smem + (t & 3) * 32768 + wr * 8192 + lane_off;
-            const unsigned char* B = smem + (t & 3) * 32768 + 16384 + wc * 4096 + lane_off;
-            bf16x8_t fa[8], fb[4];
+            const unsigned char* B = smem + (t & 3) * 32768 + 16384 + wc * (NJ * 1024) + lane_off;
+            bf16x8_t fa[8], fb[NJ];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 1024);
+            for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 1024);
 #pragma unroll
             for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 1024);
             // wr=1 waits for tile t+1 here, BEFORE it restages in its M phase: staged so far = through t+2
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)      // operands swapped: D[n][m], 4 consecutive n per lane
+            for (int j = 0; j < NJ; ++j)      // operands swapped: D[n][m], 4 consecutive n per lane
                 acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[0], acc[0][j], 0, 0, 0);
             // the restage rides in the MFMA phase: an LDS-DMA piece costs 60-180 issue cycles, which made the
             // READ phase (12 ds_read_b128 + 4 pieces) twice as long as the 512-cycle MFMA phase it overlaps
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
 #pragma unroll
             for (int i = 1; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             if (wr == 0) G2_WAIT_NEXT(t, (pair && (t & 1)) ? t + 2 : t + 3);
@@ -392,10 +394,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
         if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two groups: every LDS read is done
         __builtin_amdgcn_sched_barrier(0);
         // bias of this tile first: an ordinary load's first use drains every LDS-DMA issued before it
-        float bv[4][4];
+        float bv[NJ][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = cn0 + wc * 64 + j * 16 + fq * 4;
+        for (int j = 0; j < NJ; ++j) {
+            const int n = cn0 + wc * (16 * NJ) + j * 16 + fq * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[j][r] = 0.f;
             if ((a.N & 7) == 0 && a.bias && n < a.N) {
@@ -425,45 +427,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
         if ((a.N & 7) == 0) {
             const unsigned ebase = (unsigned)(uintptr_t)(lds_void_t*)smem + 98304u + (unsigned)wave * 4096u;
             const int rr = lane >> 3, rc = lane & 7;            // read-back: row (and row + 8), 8-column group
-            float st1[4][4], st2[4][4];
+            float st1[NJ][4], st2[NJ][4];
             if (STATS) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { st1[j][r] = 0.f; st2[j][r] = 0.f; }
             }
+            // One trip of a 16 x (16 NJ) fragment row through the wave's LDS piece: fragment layout in, line layout
+            // out (lane = row rr [+8], column octet rc: 8 lanes x 16 B cover one 128-B output line, so every store
+            // instruction writes whole lines; 4 lanes x 2 half-filled 32-B sectors per row measured 2.5 TB/s).
+            auto transpose16 = [&](const f32x4 (&v)[NJ], f32x4 (&o4)[4]) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = cm0 + wr * 128 + i * 16 + frow;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = cn0 + wc * 64 + j * 16 + fq * 4;
-                    f32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
-                    if (STATS && m < a.M) {          // statistics of what the consumer will read: the rounded values
-                        const unsigned p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
-                        const float q[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u),
-                                            __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { st1[j][r] += q[r]; st2[j][r] = fmaf(q[r], q[r], st2[j][r]); }
-                    }
-                    if (a.preact && m < a.M && n < a.N) {
-                        u32x2 pk;
-                        pk[0] = pack_bf16x2(v[0], v[1]);
-                        pk[1] = pack_bf16x2(v[2], v[3]);
-                        *reinterpret_cast<u32x2*>(a.preact + (int64_t)m * a.N + n) = pk;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = k6_act(v[r], ACT);
+                for (int j = 0; j < NJ; ++j) {
                     const unsigned wa = ebase + (unsigned)(frow * 256 + (((j * 4 + fq) ^ frow) << 4));
-                    asm volatile("ds_write_b128 %0, %1" ::"v"(wa), "v"(v) : "memory");
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(wa), "v"(v[j]) : "memory");
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                // read-back: lane = (row rr [+8], column octet rc): 8 lanes x 16 B cover one 128-B output line, so
-                // every store instruction writes whole lines (4 lanes x 2 half-filled 32-B sectors per row measured
-                // 2.5 TB/s of stores on the memory-bound 1x1-convolution shapes)
-                f32x4 o4[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int row = rr + 8 * (q >> 1);
@@ -472,33 +452,86 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                const int on = cn0 + wc * 64 + rc * 8;
+            };
+            const int on = cn0 + wc * (16 * NJ) + rc * 8;
+            const bool col_ok = on < a.N && rc < 2 * NJ;          // N % 8 == 0: an octet is all-or-nothing
+            // residual octets of fragment row i: loaded one iteration ahead, BEFORE the stores of the iteration in
+            // between -- vmcnt counts loads and stores in order, so a load issued after the stores would make its
+            // consumer wait for their write acknowledgements too (measured: +20 us on a 50 MB residual)
+            u32x4 rres[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+            auto load_res = [&](int i, u32x4 (&dst)[2]) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int om = cm0 + wr * 128 + i * 16 + rr + 8 * h;
-                    if (om < a.M && on < a.N) {          // N % 8 == 0: an octet is all-or-nothing
-                        const int64_t o = (int64_t)om * a.N + on;
+                    if (om < a.M && col_ok) dst[h] = *reinterpret_cast<const u32x4*>(a.residual + (int64_t)om * a.N + on);
+                }
+            };
+            if (a.residual) load_res(0, rres);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = cm0 + wr * 128 + i * 16 + frow;
+                f32x4 v[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[j][r] = acc[i][j][r] + bv[j][r];
+                    if (STATS && m < a.M) {          // statistics of what the consumer will read: the rounded values
+                        const unsigned p0 = pack_bf16x2(v[j][0], v[j][1]), p1 = pack_bf16x2(v[j][2], v[j][3]);
+                        const float q[4] = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u),
+                                            __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { st1[j][r] += q[r]; st2[j][r] = fmaf(q[r], q[r], st2[j][r]); }
+                    }
+                }
+                f32x4 o4[4];
+                if (a.preact && m < a.M) {          // pre-activation (saved for the backward), straight from the fragments
+                    // (a second trip through LDS for whole-line stores measured 1-7 us SLOWER per GEMM)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int n = cn0 + wc * (16 * NJ) + j * 16 + fq * 4;
+                        if (n < a.N) {
+                            u32x2 pk;
+                            pk[0] = pack_bf16x2(v[j][0], v[j][1]);
+                            pk[1] = pack_bf16x2(v[j][2], v[j][3]);
+                            *reinterpret_cast<u32x2*>(a.preact + (int64_t)m * a.N + n) = pk;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[j][r] = k6_act(v[j][r], ACT);
+                transpose16(v, o4);
+                u32x4 nres[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+                if (a.residual && i + 1 < 8) load_res(i + 1, nres);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int om = cm0 + wr * 128 + i * 16 + rr + 8 * h;
+                    if (om < a.M && col_ok) {
                         float v8[8];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { v8[k] = o4[2 * h][k]; v8[4 + k] = o4[2 * h + 1][k]; }
                         if (a.residual) {
-                            float r8[8];
-                            load8<DTF_BF16>(a.residual, o, r8);
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) v8[k] += r8[k];
+                            for (int k = 0; k < 4; ++k) {
+                                v8[2 * k] += __uint_as_float(rres[h][k] << 16);
+                                v8[2 * k + 1] += __uint_as_float(rres[h][k] & 0xffff0000u);
+                            }
                         }
-                        store8<DTF_BF16>(a.Y, o, v8);
+                        store8<DTF_BF16>(a.Y, (int64_t)om * a.N + on, v8);
                     }
                 }
+                rres[0] = nres[0];
+                rres[1] = nres[1];
             }
             if (STATS) {
                 const int blk = (cm0 / G2_BM) * 2 + wr;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     f32x4 o1, o2;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { o1[r] = row16_sum(st1[j][r]); o2[r] = row16_sum(st2[j][r]); }
-                    const int n = cn0 + wc * 64 + j * 16 + fq * 4;
+                    const int n = cn0 + wc * (16 * NJ) + j * 16 + fq * 4;
                     if (frow == 0 && n < a.N) {
                         *reinterpret_cast<f32x4*>(a.stats + ((int64_t)blk * 2 + 0) * a.N + n) = o1;
                         *reinterpret_cast<f32x4*>(a.stats + ((int64_t)blk * 2 + 1) * a.N + n) = o2;
@@ -511,10 +544,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
                 const int m = cm0 + wr * 128 + i * 16 + frow;
                 if (m >= a.M) continue;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int n = cn0 + wc * 64 + j * 16 + fq * 4 + r;
+                        const int n = cn0 + wc * (16 * NJ) + j * 16 + fq * 4 + r;
                         if (n >= a.N) continue;
                         const int64_t o = (int64_t)m * a.N + n;
                         float x = acc[i][j][r];
@@ -609,11 +642,13 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
         store1<PDT>(out, c, ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x]);
 }
 
+static int force_nj = 0;         // 3 | 4 pins the 256p tile width (DTF_GEMM_NJ)
 static int force_tile = 0;       // 128 | 256 pins the tile variant (DTF_GEMM_TILE or dtf_gemm_set_tile; A/B runs)
 
 extern "C" {
 
 void dtf_gemm_set_tile(int t) { force_tile = t; }
+void dtf_gemm_set_nj(int nj) { force_nj = nj; }
 
 int dtf_gemm_bias_act(const void* X, const void* W, const void* bias, int bias_dtype, const void* residual, void* Y,
                       void* preact, int M, int N, int K, int act, hipStream_t stream) {
@@ -630,10 +665,16 @@ int dtf_gemm_bias_act(const void* X, const void* W, const void* bias, int bias_d
     static int num_cu = 0;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_bias_act_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
-        hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_GELU_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_RELU, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_GELU, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_GELU_TANH, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_NONE, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_RELU, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_GELU, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        (void)hipFuncSetAttribute((const void*)gemm256p_kernel<ACT_GELU_TANH, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        const char* ej = getenv("DTF_GEMM_NJ");
+        if (ej) force_nj = atoi(ej);
         int dev = 0;
         hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0) num_cu = 256;
@@ -646,14 +687,28 @@ int dtf_gemm_bias_act(const void* X, const void* W, const void* bias, int bias_d
     if (force_tile == 128) big = false;
     if (force_tile == 256 && (K % 32) == 0) big = true;
     if (big) {
+        // 256 x 192 tiles where they need fewer (size-weighted) rounds over the CUs.  DTF_GEMM_NJ=3|4 pins the
+        // choice (A/B runs).
+        const int ntn3 = (N + 191) / 192;
+        const int64_t rounds4 = ((int64_t)ntm2 * ntn2 + num_cu - 1) / num_cu, rounds3 = ((int64_t)ntm2 * ntn3 + num_cu - 1) / num_cu;
+        // measured: a 256 x 192 round costs 0.84 of a 256 x 256 round (not 0.75: fewer MFMAs per A fragment read)
+        bool nj3 = (N & 7) == 0 && (double)rounds3 * 0.84 < 0.97 * (double)rounds4;
+        if (force_nj == 3) nj3 = (N & 7) == 0;
+        if (force_nj == 4) nj3 = false;
         a.ntm = ntm2;
-        a.ntn = ntn2;
-        const int ntiles = ntm2 * ntn2;
+        a.ntn = nj3 ? ntn3 : ntn2;
+        const int ntiles = a.ntm * a.ntn;
         const int grid = ntiles < num_cu ? ntiles : num_cu;
-        if (act == ACT_RELU) hipLaunchKernelGGL(gemm256p_kernel<ACT_RELU>, dim3(grid), dim3(512), lds256, stream, a, ntiles);
-        else if (act == ACT_GELU) hipLaunchKernelGGL(gemm256p_kernel<ACT_GELU>, dim3(grid), dim3(512), lds256, stream, a, ntiles);
-        else if (act == ACT_GELU_TANH) hipLaunchKernelGGL(gemm256p_kernel<ACT_GELU_TANH>, dim3(grid), dim3(512), lds256, stream, a, ntiles);
-        else hipLaunchKernelGGL(gemm256p_kernel<ACT_NONE>, dim3(grid), dim3(512), lds256, stream, a, ntiles);
+#define G2_LAUNCH(A_)                                                                                                        \
+    do {                                                                                                                     \
+        if (nj3) hipLaunchKernelGGL((gemm256p_kernel<A_, false, 3>), dim3(grid), dim3(512), lds256, stream, a, ntiles);      \
+        else hipLaunchKernelGGL((gemm256p_kernel<A_, false, 4>), dim3(grid), dim3(512), lds256, stream, a, ntiles);          \
+    } while (0)
+        if (act == ACT_RELU) G2_LAUNCH(ACT_RELU);
+        else if (act == ACT_GELU) G2_LAUNCH(ACT_GELU);
+        else if (act == ACT_GELU_TANH) G2_LAUNCH(ACT_GELU_TANH);
+        else G2_LAUNCH(ACT_NONE);
+#undef G2_LAUNCH
     } else {
         hipLaunchKernelGGL(gemm_bias_act_kernel, dim3(a.ntm * a.ntn), dim3(256), lds, stream, a);
     }

@@ -334,9 +334,10 @@ def test_gemm_bias_act_forward(dev, M, N, K, act, with_res):
         torch.testing.assert_close(pre.float(), torch.nn.functional.linear(x.float(), w.float(), b.float()), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("nj", [4, 3])
 @pytest.mark.parametrize("K", [32, 64, 96, 128, 800, 4128, 4160])
-@pytest.mark.parametrize("M,N", [(256, 256), (300, 520), (1000, 264)])
-def test_gemm_256_tile_variant(dev, M, N, K):
+@pytest.mark.parametrize("M,N", [(256, 256), (300, 520), (1000, 264), (520, 768)])
+def test_gemm_256_tile_variant(dev, M, N, K, nj):
     """The 256x256 LDS-DMA kernel forced on small problems: every pipeline prologue/tail length (1, 2, 3,
     4 K tiles), odd tile counts, the paired-staging schedule (K > 4096) and clamped edge rows."""
     import ctypes
@@ -350,12 +351,15 @@ def test_gemm_256_tile_variant(dev, M, N, K):
     w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
     b = torch.randn(N, device=dev).to(torch.bfloat16)
     r = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    set_nj = hip.declare("dtf_gemm_set_nj", [ctypes.c_int], None)
     set_tile(256)
+    set_nj(nj)                      # 256 x 256 or 256 x 192 tiles
     try:
         y, pre = lin.gemm_bias_act(x, w, b, "gelu_tanh", r, save_preact=True)
         y0, _ = lin.gemm_bias_act(x, w, None, "none")
     finally:
         set_tile(0)
+        set_nj(0)
     ref0 = x.float() @ w.float().t()
     torch.testing.assert_close(y0.float(), ref0, rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(pre.float(), ref0 + b.float(), rtol=2e-2, atol=2e-2)
@@ -375,12 +379,16 @@ def test_gemm_256_identity_layout(dev):
     N = 384
     x = torch.eye(M, K, device=dev, dtype=torch.bfloat16)
     w = ((torch.arange(N, device=dev).unsqueeze(1) * 3 + torch.arange(K, device=dev).unsqueeze(0)) % 251).to(torch.bfloat16)
+    set_nj = hip.declare("dtf_gemm_set_nj", [ctypes.c_int], None)
     set_tile(256)
     try:
-        y, _ = lin.gemm_bias_act(x, w, None, "none")
+        for nj in (4, 3):
+            set_nj(nj)
+            y, _ = lin.gemm_bias_act(x, w, None, "none")
+            assert torch.equal(y, w.t().contiguous()), nj
     finally:
         set_tile(0)
-    assert torch.equal(y, w.t().contiguous())
+        set_nj(0)
 
 
 @pytest.mark.parametrize("act", ["none", "relu", "gelu", "gelu_tanh"])
