@@ -9,6 +9,8 @@ branches average over real pixels only (TF's 'SAME' avg_pool; ``count_include_pa
 Variable names follow TF-slim's ``InceptionV3`` scope (``InceptionV3/Conv2d_1a_3x3/weights``,
 ``InceptionV3/Mixed_5b/Branch_1/Conv2d_0a_1x1/BatchNorm/beta``, ``InceptionV3/Logits/...``).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -66,6 +68,21 @@ def _pre(m, x):
     return m.conv(x), m.bn
 
 
+_POOL_AFTER_CONV = os.environ.get("DTF_POOL_AFTER_CONV", "1") != "0"      # A/B switch
+
+
+def _pool_branch(m, x):
+    """The ``AvgPool_0a_3x3 -> Conv2d_0b_1x1`` branch of a mixed block, up to its BatchNorm.  Both ops are linear
+    and act on different axes (the pool per channel over pixels -- with ``count_include_pad=False`` a per-pixel
+    weighting --, the 1x1 convolution per pixel over channels), so they commute exactly:
+    ``conv(pool(x)) == pool(conv(x))``.  Run in the second order the pooling kernels see the branch's 32..192
+    output channels instead of the block's 192..2048 input channels (4-10x less HBM traffic, forward and
+    backward); same parameters, same function up to bf16 rounding of the intermediate."""
+    if _POOL_AFTER_CONV:
+        return avg_pool2d(m.conv(x), 3, 1, 1, count_include_pad=False), m.bn
+    return m.conv(avg_pool2d(x, 3, 1, 1, count_include_pad=False)), m.bn
+
+
 class InceptionA(nn.Module):          # Mixed_5b/5c/5d
     def __init__(self, i, pool):
         super().__init__()
@@ -78,7 +95,7 @@ class InceptionA(nn.Module):          # Mixed_5b/5c/5d
         p0, x = _branch(self.b0, x)
         p1, x = _branch(self.b1, x)
         p2, x = _branch(self.b2, x)
-        return bn_act_concat([p0, p1, p2, _pre(self.b3, avg_pool2d(x, 3, 1, 1, count_include_pad=False))])
+        return bn_act_concat([p0, p1, p2, _pool_branch(self.b3, x)])
 
 
 class InceptionB(nn.Module):          # Mixed_6a (grid reduction)
@@ -107,7 +124,7 @@ class InceptionC(nn.Module):          # Mixed_6b..6e
         p0, x = _branch(self.b0, x)
         p1, x = _branch(self.b1, x)
         p2, x = _branch(self.b2, x)
-        return bn_act_concat([p0, p1, p2, _pre(self.b3, avg_pool2d(x, 3, 1, 1, count_include_pad=False))])
+        return bn_act_concat([p0, p1, p2, _pool_branch(self.b3, x)])
 
 
 class InceptionD(nn.Module):          # Mixed_7a (grid reduction)
@@ -141,7 +158,7 @@ class InceptionE(nn.Module):          # Mixed_7b/7c
         h2, x = self.b2[0].forward_fork(x)
         y2 = self.b2[1](h2)
         return bn_act_concat([p0, _pre(self.b1a, y1), _pre(self.b1b, y1), _pre(self.b2a, y2), _pre(self.b2b, y2),
-                              _pre(self.b3, avg_pool2d(x, 3, 1, 1, count_include_pad=False))])
+                              _pool_branch(self.b3, x)])
 
 
 class AuxHead(nn.Module):

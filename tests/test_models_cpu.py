@@ -51,3 +51,16 @@ def test_wide_deep_split_gradient_matches_autograd_slices():
     d3, _ = _SplitDeepWide.apply(e3, D)
     d3.backward(gd)
     assert torch.equal(e3.grad[:, :, :D].reshape(B, -1), gd) and float(e3.grad[:, :, D:].abs().max()) == 0.0
+
+
+def test_inception_pool_branch_commutes():
+    """avg-pool (count_include_pad=False) and a 1x1 convolution commute: the order used on the GPU
+    (models/inception_v3.py::_pool_branch) computes the same function as TF-slim's."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 12, 9, 7, dtype=torch.float64)
+    w = torch.randn(5, 12, 1, 1, dtype=torch.float64)
+    a = F.conv2d(F.avg_pool2d(x, 3, 1, 1, count_include_pad=False), w)
+    b = F.avg_pool2d(F.conv2d(x, w), 3, 1, 1, count_include_pad=False)
+    torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
