@@ -50,6 +50,13 @@ def main():
     ap.add_argument("--profile-dir", default="")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line, the result JSON.  Libraries write there too (RCCL prints a version banner
+    # on communicator creation), so file descriptor 1 is pointed at stderr for the run and the JSON goes to the
+    # saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from distributed_tensorflow_amd.utils import miopen as miopen_cache
 
@@ -167,7 +174,8 @@ def main():
                        "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
                        "final_loss": round(last_loss, 4)},
         }
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     comm.close()
 
 

@@ -15,6 +15,12 @@ next forward needs it (SURVEY 5.8 "reverse-layer for push").
 
 Sizing for 7 point-to-point xGMI links: a bucket of B bytes puts B/8 on every
 link, and per-link messages should be >= 1-4 MB, hence the 32 MB default.
+
+The LAST bucket is the exception (``tail_elems``): it holds the first layers, whose
+gradients appear at the very end of backward, so its push -> apply -> pull cannot hide
+behind any compute.  With 32 MB buckets ResNet-50's 51 MB of gradients left ~19 MB
+exposed every step; the first layers are therefore cut off into their own small bucket
+(a few MB: stem + the first stages) and only that is on the critical path.
 """
 from __future__ import annotations
 
@@ -47,15 +53,25 @@ class Bucket:
 
 
 class FlatLayout:
-    def __init__(self, named_numels, world, bucket_elems):
+    def __init__(self, named_numels, world, bucket_elems, tail_elems=0):
         self.world = int(world)
         self.slots = [ParamSlot(n, int(k), i) for i, (n, k) in enumerate(named_numels)]
         self.buckets = []
+        # leading (first-layer) variables that go into the small tail bucket
+        n_tail, acc = 0, 0
+        if tail_elems and tail_elems < bucket_elems:
+            for slot in self.slots:
+                acc += _round_up(slot.numel, ALIGN)
+                if acc > tail_elems:
+                    break
+                n_tail += 1
+            if n_tail == len(self.slots):
+                n_tail = 0              # the whole model fits: one ordinary bucket
         cur = Bucket(0)
         fill = 0
         for slot in reversed(self.slots):
             need = _round_up(slot.numel, ALIGN)
-            if fill and fill + need > bucket_elems:
+            if fill and (fill + need > bucket_elems or slot.index == n_tail - 1):
                 self._close(cur, fill)
                 cur = Bucket(len(self.buckets))
                 fill = 0

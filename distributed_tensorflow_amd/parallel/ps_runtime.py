@@ -91,7 +91,7 @@ def trainable(named_params):
 class ShardedPS:
     def __init__(self, named_params, comm: Comm = None, opt: OptimizerSpec = None, bucket_mb=32.0,
                  wire_dtype=None, update_mode="sync", push="reduce_scatter", overlap=True,
-                 broadcast_init=True):
+                 broadcast_init=True, tail_mb=4.0):
         self.comm = comm or Comm.single()
         self.opt = opt or OptimizerSpec()
         self.named_params = trainable(named_params)
@@ -106,8 +106,10 @@ class ShardedPS:
         W, r = self.comm.world_size, self.comm.rank
         self._dist = self.comm.live          # collectives are real (W > 1, or a forced 1-rank group)
         esize = torch.empty((), dtype=self.wire_dtype).element_size()
+        # tail_mb: size cap of the bucket holding the FIRST layers -- the only one whose push/apply/pull is
+        # exposed after backward (parallel/layout.py)
         self.layout = FlatLayout([(n, p.numel()) for n, p in self.named_params], W,
-                                 max(1, int(bucket_mb * (1 << 20) / esize)))
+                                 max(1, int(bucket_mb * (1 << 20) / esize)), int(tail_mb * (1 << 20) / esize))
         L = self.layout
         dev = self.device
         self.param_flat = torch.zeros(L.total, dtype=self.wire_dtype, device=dev)
