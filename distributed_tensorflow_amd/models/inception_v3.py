@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct, bn_act_concat
-from ..ops.conv import Conv1x1, Conv2dTN
+from ..ops.conv import Conv1x1, Conv2dTN, conv1x1
 from ..ops.pool import avg_pool2d, max_pool2d
 
 
@@ -68,6 +68,52 @@ def _pre(m, x):
     return m.conv(x), m.bn
 
 
+_FUSE_HEADS = os.environ.get("DTF_INCEPTION_FUSE_HEADS", "1") != "0"      # A/B switch
+
+
+class _SplitChannels(torch.autograd.Function):
+    """``y [N, sum(sizes), H, W]`` (NHWC) -> dense per-branch tensors; backward concatenates the branch gradients
+    into ONE tensor (autograd's own slicing would build a zero-filled full-width gradient per branch and add them)."""
+
+    @staticmethod
+    def forward(ctx, y, *sizes):
+        ctx.sizes = sizes
+        outs, a = [], 0
+        for c in sizes:
+            outs.append(y[:, a:a + c].contiguous(memory_format=torch.channels_last))
+            a += c
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros((ref.shape[0], c, ref.shape[2], ref.shape[3]))
+                 for g, c in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, 1).contiguous(memory_format=torch.channels_last),) + (None,) * len(ctx.sizes)
+
+
+def _heads(x, heads):
+    """The 1x1 convolutions that open the branches of a mixed block all read the block input: run them as ONE
+    GEMM over the concatenated filters (the input is read once instead of once per branch, the data gradient is
+    one GEMM instead of a chain of read-modify-write accumulations, the weight gradient one K6T call; the filters
+    stay separate parameters with their TF-slim names).  -> the branch pre-BatchNorm tensors, or None if the
+    block input does not qualify (CPU / fp32 runs keep the plain per-branch graph)."""
+    if not (_FUSE_HEADS and x.is_cuda and x.dtype == torch.bfloat16 and all(isinstance(m.conv, Conv1x1) for m in heads)):
+        return None
+    w = torch.cat([m.conv.weight for m in heads], 0).contiguous(memory_format=torch.channels_last)
+    y = conv1x1(x, w, mm_fwd=True)
+    return _SplitChannels.apply(y, *[m.conv.out_channels for m in heads])
+
+
+def _tail(branch, h):
+    """Rest of a Sequential branch whose head convolution output ``h`` (pre-BN) is given -> (conv_out, bn)."""
+    mods = list(branch)
+    h = mods[0].bn(h)
+    for m in mods[1:-1]:
+        h = m(h)
+    return mods[-1].conv(h), mods[-1].bn
+
+
 _POOL_AFTER_CONV = os.environ.get("DTF_POOL_AFTER_CONV", "1") != "0"      # A/B switch
 
 
@@ -92,6 +138,10 @@ class InceptionA(nn.Module):          # Mixed_5b/5c/5d
         self.b3 = ConvBN(i, pool, 1)
 
     def forward(self, x):
+        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3]) if _POOL_AFTER_CONV else None
+        if hs is not None:
+            pool = avg_pool2d(hs[3], 3, 1, 1, count_include_pad=False)
+            return bn_act_concat([(hs[0], self.b0.bn), _tail(self.b1, hs[1]), _tail(self.b2, hs[2]), (pool, self.b3.bn)])
         p0, x = _branch(self.b0, x)
         p1, x = _branch(self.b1, x)
         p2, x = _branch(self.b2, x)
@@ -121,6 +171,10 @@ class InceptionC(nn.Module):          # Mixed_6b..6e
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
+        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3]) if _POOL_AFTER_CONV else None
+        if hs is not None:
+            pool = avg_pool2d(hs[3], 3, 1, 1, count_include_pad=False)
+            return bn_act_concat([(hs[0], self.b0.bn), _tail(self.b1, hs[1]), _tail(self.b2, hs[2]), (pool, self.b3.bn)])
         p0, x = _branch(self.b0, x)
         p1, x = _branch(self.b1, x)
         p2, x = _branch(self.b2, x)
@@ -153,6 +207,13 @@ class InceptionE(nn.Module):          # Mixed_7b/7c
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
+        hs = _heads(x, [self.b0, self.b1, self.b2[0], self.b3]) if _POOL_AFTER_CONV else None
+        if hs is not None:
+            y1 = self.b1.bn(hs[1])
+            y2 = self.b2[1](self.b2[0].bn(hs[2]))
+            pool = avg_pool2d(hs[3], 3, 1, 1, count_include_pad=False)
+            return bn_act_concat([(hs[0], self.b0.bn), _pre(self.b1a, y1), _pre(self.b1b, y1), _pre(self.b2a, y2),
+                                  _pre(self.b2b, y2), (pool, self.b3.bn)])
         p0, x = _branch(self.b0, x)
         y1, x = self.b1.forward_fork(x)
         h2, x = self.b2[0].forward_fork(x)

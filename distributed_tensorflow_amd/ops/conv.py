@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 _MM_BWD_DATA_MIN_CIN = 128
 _MM_FWD_MIN_CIN = 1024
-_TN_WRW_MIN_C = 256          # K6T weight gradient when min(Cin, Cout) >= this (narrower layers waste its 256^2 tile)
+_TN_WRW_MIN_C = int(os.environ.get("DTF_CONV1X1_TN_MIN_C", "192"))      # K6T weight gradient when min(Cin, Cout) >= this
 _TN_WRW = os.environ.get("DTF_CONV1X1_TN", "1") != "0"
 _ENABLED = os.environ.get("DTF_CONV1X1_MM", "1") != "0"      # A/B switch: 0 = everything through MIOpen
 _FORK = os.environ.get("DTF_CONV1X1_FORK", "1") != "0"        # A/B switch: 0 = autograd sums the shortcut grad
@@ -50,10 +50,10 @@ def _rows(x):
 
 class _Conv1x1Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, mm_fwd=False):
         ctx.save_for_backward(x, weight)
         cout, cin = weight.shape[0], weight.shape[1]
-        if cin >= _MM_FWD_MIN_CIN:
+        if cin >= _MM_FWD_MIN_CIN or mm_fwd:
             y2 = torch.matmul(_rows(x), weight.reshape(cout, cin).t())
             N, _, H, W = x.shape
             return y2.view(N, H, W, cout).permute(0, 3, 1, 2)
@@ -66,7 +66,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
-        need_dx, need_dw = ctx.needs_input_grad
+        need_dx, need_dw = ctx.needs_input_grad[:2]
         if need_dx and cin >= _MM_BWD_DATA_MIN_CIN:
             N, _, H, W = x.shape
             dx = torch.matmul(_rows(dy), weight.reshape(cout, cin)).view(N, H, W, cin).permute(0, 3, 1, 2)
@@ -76,7 +76,7 @@ class _Conv1x1Fn(torch.autograd.Function):
                                                            [0, 0], 1, [True, False, False])
         if need_dw:
             dw = _wrw(dy, x, weight)
-        return dx, dw
+        return dx, dw, None
 
 
 # BatchNorm statistics in the K6 GEMM epilogue.  Off by default: measured on ResNet-50 batch 256
@@ -120,7 +120,7 @@ class _Conv1x1StatsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dpart):
-        return _Conv1x1Fn.backward(ctx, dy)
+        return _Conv1x1Fn.backward(ctx, dy)[:2]
 
 
 def conv1x1_stats(x, weight):
@@ -196,10 +196,12 @@ def conv1x1_fork(x, weight, own_skip_grad=False):
     return conv1x1(x, weight), x
 
 
-def conv1x1(x, weight):
+def conv1x1(x, weight, mm_fwd=False):
+    """``mm_fwd``: forward through the GEMM library whatever ``Cin`` (shapes the convolution library has no
+    tuning for, e.g. the concatenated branch heads of an Inception block)."""
     if (_ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
             and weight.shape[2] == 1 and weight.shape[3] == 1):
-        return _Conv1x1Fn.apply(x, weight)
+        return _Conv1x1Fn.apply(x, weight, mm_fwd)
     return F.conv2d(x, weight)
 
 

@@ -992,3 +992,31 @@ def test_cross_entropy_kernel_matches_reference(dev, M, V):
     l3 = logits.clone().requires_grad_()
     (ce.cross_entropy(l3, labels) * 2.5).backward()
     torch.testing.assert_close(l3.grad.float(), l2.grad * 2.5, rtol=1e-2, atol=1e-6)
+
+
+@pytest.mark.parametrize("block", ["A", "C", "E"])
+def test_inception_fused_branch_heads_match_per_branch_graph(dev, block, monkeypatch):
+    """One GEMM over the concatenated 1x1 head filters (+ the split / concatenated-gradient node) against the
+    per-branch graph: same outputs, input gradient and parameter gradients."""
+    from distributed_tensorflow_amd.models import inception_v3 as inc
+
+    torch.manual_seed(0)
+    mk = {"A": lambda: inc.InceptionA(192, 32), "C": lambda: inc.InceptionC(768, 128), "E": lambda: inc.InceptionE(1280)}[block]
+    cin = {"A": 192, "C": 768, "E": 1280}[block]
+    m = mk().to(device=dev, dtype=torch.bfloat16, memory_format=torch.channels_last).train()
+    x0 = torch.randn(8, cin, 9, 9, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = []
+    for fuse in (False, True, False):      # first pass = warm-up (MIOpen's first call may pick another solver)
+        monkeypatch.setattr(inc, "_FUSE_HEADS", fuse)
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        y = m(x * 1.0)
+        dy = torch.linspace(-1, 1, y.numel(), device=dev).view(y.shape).to(y.dtype).contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        res.append((y.detach().float(), x.grad.float(), {n: p.grad.float() for n, p in m.named_parameters()}))
+    (y1, g1, p1), (y2, g2, p2) = res[1:]
+    assert set(p1) == set(p2)
+    torch.testing.assert_close(y1, y2, rtol=3e-2, atol=3e-2)
+    assert float((g1 - g2).norm() / g2.norm()) < 0.03
+    for n in p1:
+        assert float((p1[n] - p2[n]).norm() / (p2[n].norm() + 1e-6)) < 0.12, n
