@@ -69,6 +69,7 @@ def _pre(m, x):
 
 
 _FUSE_HEADS = os.environ.get("DTF_INCEPTION_FUSE_HEADS", "1") != "0"      # A/B switch
+_SLICE_VIEWS = os.environ.get("DTF_INCEPTION_SLICE_VIEWS", "1") != "0"    # A/B switch: BN reads the head slices in place
 
 
 class _SplitChannels(torch.autograd.Function):
@@ -76,11 +77,14 @@ class _SplitChannels(torch.autograd.Function):
     into ONE tensor (autograd's own slicing would build a zero-filled full-width gradient per branch and add them)."""
 
     @staticmethod
-    def forward(ctx, y, *sizes):
+    def forward(ctx, y, dense, *sizes):
+        # dense[i]: branch i needs its own dense tensor (its consumer is not a K7 BatchNorm, which reads the
+        # channel slice of ``y`` in place through its row stride)
         ctx.sizes = sizes
         outs, a = [], 0
-        for c in sizes:
-            outs.append(y[:, a:a + c].contiguous(memory_format=torch.channels_last))
+        for c, d in zip(sizes, dense):
+            v = y[:, a:a + c]
+            outs.append(v.contiguous(memory_format=torch.channels_last) if (d or a % 8 or c % 8) else v)
             a += c
         return tuple(outs)
 
@@ -89,10 +93,10 @@ class _SplitChannels(torch.autograd.Function):
         ref = next(g for g in grads if g is not None)
         parts = [g if g is not None else ref.new_zeros((ref.shape[0], c, ref.shape[2], ref.shape[3]))
                  for g, c in zip(grads, ctx.sizes)]
-        return (torch.cat(parts, 1).contiguous(memory_format=torch.channels_last),) + (None,) * len(ctx.sizes)
+        return (torch.cat(parts, 1).contiguous(memory_format=torch.channels_last), None) + (None,) * len(ctx.sizes)
 
 
-def _heads(x, heads):
+def _heads(x, heads, dense=None):
     """The 1x1 convolutions that open the branches of a mixed block all read the block input: run them as ONE
     GEMM over the concatenated filters (the input is read once instead of once per branch, the data gradient is
     one GEMM instead of a chain of read-modify-write accumulations, the weight gradient one K6T call; the filters
@@ -102,7 +106,10 @@ def _heads(x, heads):
         return None
     w = torch.cat([m.conv.weight for m in heads], 0).contiguous(memory_format=torch.channels_last)
     y = conv1x1(x, w, mm_fwd=True)
-    return _SplitChannels.apply(y, *[m.conv.out_channels for m in heads])
+    dense = tuple(dense) if dense is not None else (not _SLICE_VIEWS,) * len(heads)
+    if not _SLICE_VIEWS:
+        dense = (True,) * len(heads)
+    return _SplitChannels.apply(y, dense, *[m.conv.out_channels for m in heads])
 
 
 def _tail(branch, h):
@@ -138,7 +145,7 @@ class InceptionA(nn.Module):          # Mixed_5b/5c/5d
         self.b3 = ConvBN(i, pool, 1)
 
     def forward(self, x):
-        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3]) if _POOL_AFTER_CONV else None
+        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3], dense=(False, False, False, True)) if _POOL_AFTER_CONV else None
         if hs is not None:
             pool = avg_pool2d(hs[3], 3, 1, 1, count_include_pad=False)
             return bn_act_concat([(hs[0], self.b0.bn), _tail(self.b1, hs[1]), _tail(self.b2, hs[2]), (pool, self.b3.bn)])
@@ -171,7 +178,7 @@ class InceptionC(nn.Module):          # Mixed_6b..6e
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
-        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3]) if _POOL_AFTER_CONV else None
+        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3], dense=(False, False, False, True)) if _POOL_AFTER_CONV else None
         if hs is not None:
             pool = avg_pool2d(hs[3], 3, 1, 1, count_include_pad=False)
             return bn_act_concat([(hs[0], self.b0.bn), _tail(self.b1, hs[1]), _tail(self.b2, hs[2]), (pool, self.b3.bn)])
@@ -207,7 +214,7 @@ class InceptionE(nn.Module):          # Mixed_7b/7c
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
-        hs = _heads(x, [self.b0, self.b1, self.b2[0], self.b3]) if _POOL_AFTER_CONV else None
+        hs = _heads(x, [self.b0, self.b1, self.b2[0], self.b3], dense=(False, False, False, True)) if _POOL_AFTER_CONV else None
         if hs is not None:
             y1 = self.b1.bn(hs[1])
             y2 = self.b2[1](self.b2[0].bn(hs[2]))

@@ -28,10 +28,10 @@ def _lib():
         P, I, L, Fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
         hip.declare("dtf_bn_partial_floats", [L, I], L)
         hip.declare("dtf_bn_mask_bytes", [L, I], L)
-        hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, L, P])
+        hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, L, L, P])
         hip.declare("dtf_bn_fwd_train_pre", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, I, L, I, I, L, P])
         hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, P, L, I, I, P])
-        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, P])
+        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, L, P])
         _declared = True
     return lib
 
@@ -62,9 +62,22 @@ def _nhwc_rows(x):
     return None
 
 
+def _row_stride(x):
+    """Row stride (elements) of an NHWC activation the kernels can read in place: ``C`` for a dense tensor, the
+    parent's channel count for a channel slice ``parent[:, a:b]`` of a dense NHWC tensor; None otherwise."""
+    if _nhwc_rows(x) is not None:
+        return x.shape[1]
+    if x.dim() == 4:
+        N, C, H, W = x.shape
+        sn, sc, sh, sw = x.stride()
+        if sc == 1 and sw >= C and sw % 8 == 0 and sh == W * sw and (sn == H * W * sw or N == 1) and x.data_ptr() % 16 == 0:
+            return sw
+    return None
+
+
 def kernel_eligible(x, weight):
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype in (torch.bfloat16, torch.float32)
-            and _nhwc_rows(x) is not None and x.shape[1] % 8 == 0 and x.shape[1] <= 5000 and x.numel() > 0)
+            and _row_stride(x) is not None and x.shape[1] % 8 == 0 and x.shape[1] <= 5000 and x.numel() > 0)
 
 
 class _FusedBNAct(torch.autograd.Function):
@@ -73,9 +86,12 @@ class _FusedBNAct(torch.autograd.Function):
         # pre: fp32 [nblk, 2, C] column sums / sums of squares of x from its producer (K6 STATS epilogue,
         # ops/conv.py conv1x1_stats) -- the statistics pass over x is skipped
         lib = _lib()
-        M, C = _nhwc_rows(x)
+        ldx = _row_stride(x)             # > C: x is a channel slice of a wider NHWC tensor, read in place
+        C = x.shape[1]
+        M = x.numel() // C
         dev = x.device
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, dtype=x.dtype, device=dev, memory_format=torch.channels_last) if x.dim() == 4 \
+            else torch.empty_like(x)
         stats = torch.empty(4, C, dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
         mask = None
         if residual is not None:
@@ -83,6 +99,7 @@ class _FusedBNAct(torch.autograd.Function):
             if relu:
                 mask = torch.empty(int(lib.dtf_bn_mask_bytes(M, C)), dtype=torch.uint8, device=dev)
         if pre is not None:
+            assert ldx == C
             assert pre.dtype == torch.float32 and pre.dim() == 3 and pre.shape[1] == 2 and pre.shape[2] == C and pre.is_contiguous()
             rc = lib.dtf_bn_fwd_train_pre(
                 hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
@@ -94,12 +111,12 @@ class _FusedBNAct(torch.autograd.Function):
                 hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
                 hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
                 stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-                hip.ptr(_partial(dev, M, C)), M, C, int(relu), 0, hip.stream())
+                hip.ptr(_partial(dev, M, C)), M, C, int(relu), 0, ldx, hip.stream())
         hip.check(rc, "dtf_bn_fwd_train")
         ctx.save_for_backward(x, mask, weight, stats)
         # ReLU mask source for backward: 1 = recompute from x (no residual), 3 = bit mask
         ctx.relu_mode = 0 if not relu else (3 if residual is not None else 1)
-        ctx.has_res, ctx.dims = residual is not None, (M, C)
+        ctx.has_res, ctx.dims, ctx.ldx = residual is not None, (M, C), ldx
         return y
 
     @staticmethod
@@ -108,17 +125,17 @@ class _FusedBNAct(torch.autograd.Function):
         M, C = ctx.dims
         lib = _lib()
         dev = x.device
-        if _nhwc_rows(dy) is None or dy.stride() != x.stride():
+        if _nhwc_rows(dy) is None:
             dy = dy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else dy.contiguous()
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if ctx.has_res else None
+        dx = torch.empty_like(dy)
+        dres = torch.empty_like(dy) if ctx.has_res else None
         dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
         coef = torch.empty(3, C, dtype=torch.float32, device=dev)
         rc = lib.dtf_bn_bwd_train(
             hip.ptr(dy), hip.ptr(x), hip.ptr(mask), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
             stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), hip.ptr(dres),
             dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
-            int(ctx.relu_mode), 0, hip.stream())
+            int(ctx.relu_mode), 0, ctx.ldx, hip.stream())
         hip.check(rc, "dtf_bn_bwd_train")
         return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None
 
@@ -151,7 +168,7 @@ class _BNConcat(torch.autograd.Function):
                 hip.ptr(x), None, out.data_ptr() + off * 2, None, hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
                 hip.ptr(rm), hip.ptr(rv), float(momentum), float(eps),
                 stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-                hip.ptr(_partial(dev, M, C)), M, C, int(relu), Ct, hip.stream())
+                hip.ptr(_partial(dev, M, C)), M, C, int(relu), Ct, _row_stride(x), hip.stream())
             hip.check(rc, "dtf_bn_fwd_train (concat)")
             saved += [x, weight, stats]
             off += C
@@ -174,14 +191,14 @@ class _BNConcat(torch.autograd.Function):
         for i in range(nb):
             x, weight, stats = ctx.saved_tensors[3 * i:3 * i + 3]
             C = chans[i]
-            dx = torch.empty_like(x)
+            dx = torch.empty(x.shape, dtype=x.dtype, device=dev, memory_format=torch.channels_last)
             dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
             coef = torch.empty(3, C, dtype=torch.float32, device=dev)
             rc = lib.dtf_bn_bwd_train(
                 dout.data_ptr() + off * 2, hip.ptr(x), None, hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
                 stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), None,
                 dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
-                1 if ctx.relu else 0, Ct, hip.stream())
+                1 if ctx.relu else 0, Ct, _row_stride(x), hip.stream())
             hip.check(rc, "dtf_bn_bwd_train (concat)")
             grads += [dx, dgb[0], dgb[1], None, None, None, None]
             off += C
@@ -235,6 +252,8 @@ def fused_bn_act(x, weight, bias, residual=None, running_mean=None, running_var=
         return _FusedBNAct.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu, stats)
     # inference: statistics are constants -> a single fused apply pass
     lib = _lib()
+    if _nhwc_rows(x) is None:          # a channel-slice view: the apply-only entry point reads dense rows
+        x = x.contiguous(memory_format=torch.channels_last)
     M, C = _nhwc_rows(x)
     scale = weight.float() * torch.rsqrt(running_var.float() + eps)
     shift = bias.float() - running_mean.float() * scale

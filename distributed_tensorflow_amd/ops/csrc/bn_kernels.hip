@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         float* __restrict__ partial, int64_t M, int C,
-                                                        int rows_per_block, int64_t lddy) {
+                                                        int rows_per_block, int64_t lddy, int64_t ldx) {
     const int tx = threadIdx.x & 7;
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                 const int64_t row = r + (int64_t)u * BN_ROWS;
                 ok[u] = row < r1;
                 if (ok[u]) {
-                    const int64_t off = row * C + c0;
-                    ld8bf(x + off, xv[u]);
+                    ld8bf(x + row * ldx + c0, xv[u]);
                     if (MODE != BN_FWD_STATS) ld8bf(dy + row * lddy + c0, dv[u]);
                     if (MODE == BN_BWD_RELU_MASK) mb[u] = mrow[row * 8];
                 }
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const unsigned short*
                                                            const float* __restrict__ shift,
                                                            unsigned short* __restrict__ y,
                                                            unsigned char* __restrict__ mask, int64_t M, int C,
-                                                           int rows_per_block, int64_t ldy) {
+                                                           int rows_per_block, int64_t ldy, int64_t ldx) {
     const int tx = threadIdx.x & 7;
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const unsigned short*
             const int64_t row = r + (int64_t)u * BN_ROWS;
             ok[u] = row < r1;
             if (ok[u]) {
-                ld8bf(x + row * C + c0, xv[u]);
+                ld8bf(x + row * ldx + c0, xv[u]);
                 if (RES) ld8bf(res + row * C + c0, rv[u]);
             }
         }
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
                                                            const float* __restrict__ coef,
                                                            unsigned short* __restrict__ dx,
                                                            unsigned short* __restrict__ dres, int64_t M, int C,
-                                                           int rows_per_block, int64_t lddy) {
+                                                           int rows_per_block, int64_t lddy, int64_t ldx) {
     const int tx = threadIdx.x & 7;
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
             ok[u] = row < r1;
             if (ok[u]) {
                 ld8bf(dy + row * lddy + c0, dv[u]);
-                ld8bf(x + row * C + c0, xv[u]);
+                ld8bf(x + row * ldx + c0, xv[u]);
                 if (MODE == BN_BWD_RELU_MASK) mb[u] = mrow[row * 8];
             }
         }
@@ -395,13 +394,13 @@ int64_t dtf_bn_partial_floats(int64_t M, int C) {
 int64_t dtf_bn_mask_bytes(int64_t M, int C) { return (int64_t)((C + BN_CT - 1) / BN_CT) * M * 8; }
 
 static void launch_fwd_apply(const void* x, const void* res, void* y, void* mask, const float* scale,
-                             const float* shift, int64_t M, int C, int relu, int64_t ldy, hipStream_t stream) {
+                             const float* shift, int64_t M, int C, int relu, int64_t ldy, int64_t ldx, hipStream_t stream) {
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
     const unsigned short *xs = (const unsigned short*)x, *rs = (const unsigned short*)res;
     unsigned short* ys = (unsigned short*)y;
     unsigned char* ms = (unsigned char*)mask;
-#define FWD(R, S) hipLaunchKernelGGL((bn_fwd_apply_kernel<R, S>), dim3(nb, ct), dim3(256), 0, stream, xs, rs, scale, shift, ys, ms, M, C, rpb, ldy)
+#define FWD(R, S) hipLaunchKernelGGL((bn_fwd_apply_kernel<R, S>), dim3(nb, ct), dim3(256), 0, stream, xs, rs, scale, shift, ys, ms, M, C, rpb, ldy, ldx)
     if (relu) { if (res) FWD(true, true); else FWD(true, false); }
     else { if (res) FWD(false, true); else FWD(false, false); }
 #undef FWD
@@ -413,18 +412,21 @@ static void launch_fwd_apply(const void* x, const void* res, void* y, void* mask
 int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const void* gamma, const void* beta,
                      int param_dtype, float* running_mean, float* running_var, float momentum, float eps,
                      float* mean, float* invstd, float* scale, float* shift, float* partial, int64_t M, int C,
-                     int relu, int64_t ldy, hipStream_t stream) {
+                     int relu, int64_t ldy, int64_t ldx, hipStream_t stream) {
+    // ldx: row stride (elements) of x -- C for a dense tensor, the total channel count when x is a channel slice
+    // of a wider NHWC tensor (a branch of a fused multi-head convolution output read in place)
     // ldy: row stride (elements) of y -- C for a dense tensor, the total channel count when y is a
     // channel slice of a wider NHWC tensor (branch outputs written straight into a concat buffer)
     DTF_CLEAR_ERRORS();
     if (C % 8 != 0 || M <= 0) return -20;
     if (ldy == 0) ldy = C;
-    if (ldy < C || (ldy & 7)) return -24;
+    if (ldx == 0) ldx = C;
+    if (ldy < C || (ldy & 7) || ldx < C || (ldx & 7)) return -24;
     if (relu && res && !mask) return -22;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
     hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream,
-                       (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, nullptr, partial, M, C, rpb, (int64_t)C);
+                       (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, nullptr, partial, M, C, rpb, (int64_t)C, ldx);
     const float inv_count = 1.0f / (float)M;
     const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
     const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
@@ -436,7 +438,7 @@ int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const 
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
                            inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
                            scale, shift);
-    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, ldy, stream);
+    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, ldy, ldx, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -463,7 +465,7 @@ int dtf_bn_fwd_train_pre(const void* x, const void* res, void* y, void* mask, co
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C,
                            inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
                            scale, shift);
-    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, ldy, stream);
+    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, ldy, (int64_t)C, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -474,7 +476,7 @@ int dtf_bn_fwd_apply(const void* x, const void* res, void* y, void* mask, const 
     DTF_CLEAR_ERRORS();
     if (C % 8 != 0 || M <= 0) return -20;
     if (relu && res && !mask) return -22;
-    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, (int64_t)C, stream);
+    launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, (int64_t)C, (int64_t)C, stream);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -485,18 +487,19 @@ int dtf_bn_fwd_apply(const void* x, const void* res, void* y, void* mask, const 
 int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void* gamma, int param_dtype,
                      const float* mean, const float* invstd, const float* scale, const float* shift, void* dx,
                      void* dres, void* dgamma, void* dbeta, float* coef, float* partial, int64_t M, int C,
-                     int relu_mode, int64_t lddy, hipStream_t stream) {
+                     int relu_mode, int64_t lddy, int64_t ldx, hipStream_t stream) {
     // lddy: row stride (elements) of dy (a channel slice of the concat gradient is read in place)
     DTF_CLEAR_ERRORS();
     if (C % 8 != 0 || M <= 0) return -20;
     if (lddy == 0) lddy = C;
-    if (lddy < C || (lddy & 7)) return -24;
+    if (ldx == 0) ldx = C;
+    if (lddy < C || (lddy & 7) || ldx < C || (ldx & 7)) return -24;
     if (relu_mode == BN_BWD_RELU_MASK && !mask) return -22;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
     const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x;
     const unsigned char* ms = (const unsigned char*)mask;
-#define RED(MODE) hipLaunchKernelGGL((bn_reduce_kernel<MODE, BN_UNROLL>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, rpb, lddy)
+#define RED(MODE) hipLaunchKernelGGL((bn_reduce_kernel<MODE, BN_UNROLL>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, rpb, lddy, ldx)
     if (relu_mode == BN_BWD_RELU_X) RED(BN_BWD_RELU_X);
     else if (relu_mode == BN_BWD_RELU_MASK) RED(BN_BWD_RELU_MASK);
     else RED(BN_BWD_PLAIN);
@@ -510,7 +513,7 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
         hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
                            inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
     unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
-#define BWD(MODE, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<MODE, S>), dim3(nb, ct), dim3(256), 0, stream, dys, xs, ms, scale, shift, coef, dxs, drs, M, C, rpb, lddy)
+#define BWD(MODE, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<MODE, S>), dim3(nb, ct), dim3(256), 0, stream, dys, xs, ms, scale, shift, coef, dxs, drs, M, C, rpb, lddy, ldx)
     if (relu_mode == BN_BWD_RELU_X) { if (dres) BWD(BN_BWD_RELU_X, true); else BWD(BN_BWD_RELU_X, false); }
     else if (relu_mode == BN_BWD_RELU_MASK) { if (dres) BWD(BN_BWD_RELU_MASK, true); else BWD(BN_BWD_RELU_MASK, false); }
     else { if (dres) BWD(BN_BWD_PLAIN, true); else BWD(BN_BWD_PLAIN, false); }

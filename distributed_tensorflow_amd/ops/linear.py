@@ -83,6 +83,7 @@ def gemm_bias_act(x2, weight, bias, act, residual=None, save_preact=False):
 _tn_ws = {}
 _TN_DISABLED = _os.environ.get("DTF_GEMM_TN", "1") == "0"        # A/B switch
 _TN_FUSE_BIAS = _os.environ.get("DTF_TN_FUSE_BIAS", "1") != "0"  # A/B switch
+_PLAIN_LIB = _os.environ.get("DTF_LINEAR_PLAIN_LIB", "1") != "0"  # A/B switch: bias-only forward GEMMs through the library
 
 
 def gemm_tn_eligible(a, b):
@@ -128,7 +129,12 @@ class _FusedLinear(torch.autograd.Function):
         r2 = None
         if residual is not None:
             r2 = residual.reshape(-1, weight.shape[0]).contiguous()
-        y, pre = gemm_bias_act(x2, weight, bias, act, r2, save_preact=(act in _GELUS))
+        if _PLAIN_LIB and act in ("none", None) and r2 is None and bias is not None and bias.dtype == x2.dtype:
+            # nothing to fuse but the bias, which the GEMM library's own epilogue adds: 113 vs 136 us on BERT's
+            # QKV projection (scripts/k6_epilogue_bench.py)
+            y, pre = torch.addmm(bias, x2, weight.t()), None
+        else:
+            y, pre = gemm_bias_act(x2, weight, bias, act, r2, save_preact=(act in _GELUS))
         z = y if act == "relu" else pre      # relu: mask = y > 0 (fused_linear keeps relu+residual unfused)
         ctx.save_for_backward(x2, weight, z)
         ctx.act, ctx.has_bias, ctx.has_res, ctx.shape = act, bias is not None, residual is not None, shp

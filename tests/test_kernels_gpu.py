@@ -1020,3 +1020,35 @@ def test_inception_fused_branch_heads_match_per_branch_graph(dev, block, monkeyp
     assert float((g1 - g2).norm() / g2.norm()) < 0.03
     for n in p1:
         assert float((p1[n] - p2[n]).norm() / (p2[n].norm() + 1e-6)) < 0.12, n
+
+
+@pytest.mark.parametrize("with_res", [False, True])
+def test_batchnorm_reads_a_channel_slice_in_place(dev, with_res):
+    """K7 on ``parent[:, a:b]`` of a wider NHWC tensor (row stride = parent channels) is bitwise the same as on a
+    dense copy of the slice, forward and backward."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod
+
+    torch.manual_seed(0)
+    N, Ct, H, W, a, b = 4, 208, 9, 11, 64, 112
+    parent = torch.randn(N, Ct, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(N, b - a, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) if with_res else None
+    dy = torch.randn(N, b - a, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for dense in (False, True):
+        bn = bnmod.FusedBatchNormAct(b - a, relu=True).to(dev).to(torch.bfloat16).train()
+        torch.manual_seed(1)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.5, 0.5)
+        p = parent.clone().requires_grad_()
+        x = p[:, a:b]
+        if dense:
+            x = x.contiguous(memory_format=torch.channels_last)
+        else:
+            assert bnmod._row_stride(x) == Ct and bnmod.kernel_eligible(x, bn.weight)
+        y = bn(x, res)
+        assert y.is_contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        outs.append((y.detach().clone(), p.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone()))
+    for t1, t2 in zip(*outs):
+        assert torch.equal(t1, t2)
