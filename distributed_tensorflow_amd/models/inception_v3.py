@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops.batchnorm import FusedBatchNormAct, bn_act_concat
+from ..ops.batchnorm import FusedBatchNormAct, GradSlices, bn_act_concat
 from ..ops.conv import Conv1x1, Conv2dTN, conv1x1
 from ..ops.pool import avg_pool2d, max_pool2d
 
@@ -69,6 +69,7 @@ def _pre(m, x):
 
 
 _FUSE_HEADS = os.environ.get("DTF_INCEPTION_FUSE_HEADS", "1") != "0"      # A/B switch
+_GRAD_IN_PLACE = os.environ.get("DTF_INCEPTION_GRAD_IN_PLACE", "1") != "0"  # A/B switch: BN dx into the shared buffer
 _SLICE_VIEWS = os.environ.get("DTF_INCEPTION_SLICE_VIEWS", "1") != "0"    # A/B switch: BN reads the head slices in place
 
 
@@ -77,7 +78,8 @@ class _SplitChannels(torch.autograd.Function):
     into ONE tensor (autograd's own slicing would build a zero-filled full-width gradient per branch and add them)."""
 
     @staticmethod
-    def forward(ctx, y, dense, *sizes):
+    def forward(ctx, y, dense, prov, *sizes):
+        ctx.prov = prov
         # dense[i]: branch i needs its own dense tensor (its consumer is not a K7 BatchNorm, which reads the
         # channel slice of ``y`` in place through its row stride)
         ctx.sizes = sizes
@@ -90,10 +92,18 @@ class _SplitChannels(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        ref = next(g for g in grads if g is not None)
-        parts = [g if g is not None else ref.new_zeros((ref.shape[0], c, ref.shape[2], ref.shape[3]))
-                 for g, c in zip(grads, ctx.sizes)]
-        return (torch.cat(parts, 1).contiguous(memory_format=torch.channels_last), None) + (None,) * len(ctx.sizes)
+        # the K7 BatchNorm layers that read a slice in place have already written their dx into the shared buffer
+        # (ops/batchnorm.py::GradSlices); everything else is copied into its slice
+        prov = ctx.prov
+        buf, a = prov.get(), 0
+        for g, c in zip(grads, ctx.sizes):
+            if g is None:
+                buf[:, a:a + c].zero_()
+            elif not prov.holds(g, a, c):
+                buf[:, a:a + c].copy_(g)
+            a += c
+        prov.release()
+        return (buf, None, None) + (None,) * len(ctx.sizes)
 
 
 def _heads(x, heads, dense=None):
@@ -109,7 +119,14 @@ def _heads(x, heads, dense=None):
     dense = tuple(dense) if dense is not None else (not _SLICE_VIEWS,) * len(heads)
     if not _SLICE_VIEWS:
         dense = (True,) * len(heads)
-    return _SplitChannels.apply(y, dense, *[m.conv.out_channels for m in heads])
+    prov = GradSlices(y.shape, y.dtype, y.device)
+    outs = _SplitChannels.apply(y, dense, prov, *[m.conv.out_channels for m in heads])
+    a = 0
+    for o, d, m in zip(outs, dense, heads):
+        if not d and _GRAD_IN_PLACE:
+            o._dtf_gradslot = (prov, a, m.conv.out_channels)
+        a += m.conv.out_channels
+    return outs
 
 
 def _tail(branch, h):

@@ -31,7 +31,7 @@ def _lib():
         hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, L, L, P])
         hip.declare("dtf_bn_fwd_train_pre", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, I, L, I, I, L, P])
         hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, P, L, I, I, P])
-        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, L, P])
+        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, L, L, P])
         _declared = True
     return lib
 
@@ -73,6 +73,44 @@ def _row_stride(x):
         if sc == 1 and sw >= C and sw % 8 == 0 and sh == W * sw and (sn == H * W * sw or N == 1) and x.data_ptr() % 16 == 0:
             return sw
     return None
+
+
+class GradSlices:
+    """Shared gradient buffer of a tensor whose channel slices feed several K7 BatchNorm layers (the fused branch
+    heads of an Inception block).  The producer of the slices attaches ``(provider, offset, channels)`` to each
+    slice as ``_dtf_gradslot``; the BatchNorm backward then writes its ``dx`` straight into that slice of ONE
+    buffer (row stride = total channels) and the producer's backward returns the buffer -- no concatenation pass."""
+
+    def __init__(self, shape, dtype, device):
+        self.shape, self.dtype, self.device = tuple(shape), dtype, device
+        self.buffer = None
+
+    def get(self):
+        if self.buffer is None:
+            self.buffer = torch.empty(self.shape, dtype=self.dtype, device=self.device, memory_format=torch.channels_last)
+        return self.buffer
+
+    def slice(self, off, c):
+        return self.get()[:, off:off + c]
+
+    def holds(self, g, off, c):
+        b = self.buffer
+        return (b is not None and g is not None and g.data_ptr() == b.data_ptr() + off * b.element_size()
+                and g.shape[1] == c and g.stride() == b.stride())
+
+    def release(self):
+        self.buffer = None
+
+
+def _dx_target(x, like):
+    """-> (dx tensor, row stride) for the gradient of BatchNorm input ``x``."""
+    slot = getattr(x, "_dtf_gradslot", None)
+    if slot is not None:
+        prov, off, c = slot
+        if prov.shape[1] % 8 == 0 and off % 8 == 0 and c == like.shape[1] and prov.dtype == like.dtype:
+            return prov.slice(off, c), prov.shape[1]
+    return torch.empty(like.shape, dtype=like.dtype, device=like.device, memory_format=torch.channels_last) \
+        if like.dim() == 4 else torch.empty_like(like), like.shape[1]
 
 
 def kernel_eligible(x, weight):
@@ -117,6 +155,7 @@ class _FusedBNAct(torch.autograd.Function):
         # ReLU mask source for backward: 1 = recompute from x (no residual), 3 = bit mask
         ctx.relu_mode = 0 if not relu else (3 if residual is not None else 1)
         ctx.has_res, ctx.dims, ctx.ldx = residual is not None, (M, C), ldx
+        ctx.gradslot = getattr(x, "_dtf_gradslot", None)
         return y
 
     @staticmethod
@@ -127,7 +166,9 @@ class _FusedBNAct(torch.autograd.Function):
         dev = x.device
         if _nhwc_rows(dy) is None:
             dy = dy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 else dy.contiguous()
-        dx = torch.empty_like(dy)
+        if ctx.gradslot is not None:
+            x._dtf_gradslot = ctx.gradslot
+        dx, lddx = _dx_target(x, dy)
         dres = torch.empty_like(dy) if ctx.has_res else None
         dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
         coef = torch.empty(3, C, dtype=torch.float32, device=dev)
@@ -135,7 +176,7 @@ class _FusedBNAct(torch.autograd.Function):
             hip.ptr(dy), hip.ptr(x), hip.ptr(mask), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
             stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), hip.ptr(dres),
             dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
-            int(ctx.relu_mode), 0, ctx.ldx, hip.stream())
+            int(ctx.relu_mode), 0, ctx.ldx, lddx, hip.stream())
         hip.check(rc, "dtf_bn_bwd_train")
         return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None
 
@@ -160,7 +201,7 @@ class _BNConcat(torch.autograd.Function):
         Ct = sum(chans)
         out = torch.empty((N, Ct, H, W), dtype=x0.dtype, device=dev, memory_format=torch.channels_last)
         M = N * H * W
-        saved, off = [], 0
+        saved, off, slots = [], 0, []
         for x, weight, bias, rm, rv, momentum, eps in branches:
             C = x.shape[1]
             stats = torch.empty(4, C, dtype=torch.float32, device=dev)
@@ -171,12 +212,13 @@ class _BNConcat(torch.autograd.Function):
                 hip.ptr(_partial(dev, M, C)), M, C, int(relu), Ct, _row_stride(x), hip.stream())
             hip.check(rc, "dtf_bn_fwd_train (concat)")
             saved += [x, weight, stats]
+            slots.append(getattr(x, "_dtf_gradslot", None))
             off += C
         for e in extra:
             out.narrow(1, off, e.shape[1]).copy_(e)
             off += e.shape[1]
         ctx.save_for_backward(*saved)
-        ctx.nb, ctx.relu, ctx.chans, ctx.M = nb, relu, chans, M
+        ctx.nb, ctx.relu, ctx.chans, ctx.M, ctx.slots = nb, relu, chans, M, slots
         return out
 
     @staticmethod
@@ -191,14 +233,16 @@ class _BNConcat(torch.autograd.Function):
         for i in range(nb):
             x, weight, stats = ctx.saved_tensors[3 * i:3 * i + 3]
             C = chans[i]
-            dx = torch.empty(x.shape, dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            if ctx.slots[i] is not None:
+                x._dtf_gradslot = ctx.slots[i]
+            dx, lddx = _dx_target(x, x)
             dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
             coef = torch.empty(3, C, dtype=torch.float32, device=dev)
             rc = lib.dtf_bn_bwd_train(
                 dout.data_ptr() + off * 2, hip.ptr(x), None, hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
                 stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), None,
                 dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
-                1 if ctx.relu else 0, Ct, _row_stride(x), hip.stream())
+                1 if ctx.relu else 0, Ct, _row_stride(x), lddx, hip.stream())
             hip.check(rc, "dtf_bn_bwd_train (concat)")
             grads += [dx, dgb[0], dgb[1], None, None, None, None]
             off += C

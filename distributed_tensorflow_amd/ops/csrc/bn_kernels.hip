@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
                                                            const float* __restrict__ coef,
                                                            unsigned short* __restrict__ dx,
                                                            unsigned short* __restrict__ dres, int64_t M, int C,
-                                                           int rows_per_block, int64_t lddy, int64_t ldx) {
+                                                           int rows_per_block, int64_t lddy, int64_t ldx, int64_t lddx) {
     const int tx = threadIdx.x & 7;
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
                 dv[u][k] = d;
                 xv[u][k] = fmaf(k1[k], d, fmaf(k2[k], xv[u][k], k3[k]));
             }
-            st8bf(dx + row * C + c0, xv[u]);
+            st8bf(dx + row * lddx + c0, xv[u]);
             if (RES) st8bf(dres + row * C + c0, dv[u]);
         }
     }
@@ -487,13 +487,15 @@ int dtf_bn_fwd_apply(const void* x, const void* res, void* y, void* mask, const 
 int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void* gamma, int param_dtype,
                      const float* mean, const float* invstd, const float* scale, const float* shift, void* dx,
                      void* dres, void* dgamma, void* dbeta, float* coef, float* partial, int64_t M, int C,
-                     int relu_mode, int64_t lddy, int64_t ldx, hipStream_t stream) {
+                     int relu_mode, int64_t lddy, int64_t ldx, int64_t lddx, hipStream_t stream) {
+    // lddx: row stride of dx (written into a channel slice of a wider gradient tensor when > C)
     // lddy: row stride (elements) of dy (a channel slice of the concat gradient is read in place)
     DTF_CLEAR_ERRORS();
     if (C % 8 != 0 || M <= 0) return -20;
     if (lddy == 0) lddy = C;
     if (ldx == 0) ldx = C;
-    if (lddy < C || (lddy & 7) || ldx < C || (ldx & 7)) return -24;
+    if (lddx == 0) lddx = C;
+    if (lddy < C || (lddy & 7) || ldx < C || (ldx & 7) || lddx < C || (lddx & 7)) return -24;
     if (relu_mode == BN_BWD_RELU_MASK && !mask) return -22;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
@@ -513,7 +515,7 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
         hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
                            inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
     unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
-#define BWD(MODE, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<MODE, S>), dim3(nb, ct), dim3(256), 0, stream, dys, xs, ms, scale, shift, coef, dxs, drs, M, C, rpb, lddy, ldx)
+#define BWD(MODE, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<MODE, S>), dim3(nb, ct), dim3(256), 0, stream, dys, xs, ms, scale, shift, coef, dxs, drs, M, C, rpb, lddy, ldx, lddx)
     if (relu_mode == BN_BWD_RELU_X) { if (dres) BWD(BN_BWD_RELU_X, true); else BWD(BN_BWD_RELU_X, false); }
     else if (relu_mode == BN_BWD_RELU_MASK) { if (dres) BWD(BN_BWD_RELU_MASK, true); else BWD(BN_BWD_RELU_MASK, false); }
     else { if (dres) BWD(BN_BWD_PLAIN, true); else BWD(BN_BWD_PLAIN, false); }
