@@ -69,6 +69,7 @@ def _pre(m, x):
 
 
 _FUSE_HEADS = os.environ.get("DTF_INCEPTION_FUSE_HEADS", "1") != "0"      # A/B switch
+_HEADS_MM = os.environ.get("DTF_INCEPTION_HEADS_MM", "0") != "0"          # fused heads forward: GEMM library (1) / MIOpen (0)
 _GRAD_IN_PLACE = os.environ.get("DTF_INCEPTION_GRAD_IN_PLACE", "1") != "0"  # A/B switch: BN dx into the shared buffer
 _SLICE_VIEWS = os.environ.get("DTF_INCEPTION_SLICE_VIEWS", "1") != "0"    # A/B switch: BN reads the head slices in place
 
@@ -115,7 +116,7 @@ def _heads(x, heads, dense=None):
     if not (_FUSE_HEADS and x.is_cuda and x.dtype == torch.bfloat16 and all(isinstance(m.conv, Conv1x1) for m in heads)):
         return None
     w = torch.cat([m.conv.weight for m in heads], 0).contiguous(memory_format=torch.channels_last)
-    y = conv1x1(x, w, mm_fwd=True)
+    y = conv1x1(x, w, mm_fwd=_HEADS_MM)
     dense = tuple(dense) if dense is not None else (not _SLICE_VIEWS,) * len(heads)
     if not _SLICE_VIEWS:
         dense = (True,) * len(heads)
