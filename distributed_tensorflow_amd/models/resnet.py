@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..ops.batchnorm import FusedBatchNormAct
+from ..ops.batchnorm import FusedBatchNormAct, fused_bn2_add_relu
 from ..ops.conv import Conv1x1, Conv2dTN
 from ..ops.pool import max_pool2d
 
@@ -58,6 +58,11 @@ class Bottleneck(nn.Module):
             y, x = self.conv1.forward_fork(x, own_skip_grad=True)
         else:
             y = self.conv1(x)
+        if self.shortcut_conv is not None and self.training and x.is_cuda:
+            # both BatchNorms, the add and the ReLU of a stage's first block in one K7 node
+            s = self.shortcut_conv(x)
+            y = self.bn2(self.conv2(self.bn1(y)))
+            return fused_bn2_add_relu(self.conv3(y), self.bn3, s, self.shortcut_bn)
         if self.shortcut_conv is None:
             sc = x
         elif isinstance(self.shortcut_conv, Conv1x1):

@@ -30,6 +30,8 @@ def _lib():
         hip.declare("dtf_bn_mask_bytes", [L, I], L)
         hip.declare("dtf_bn_fwd_train", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, I, L, L, P])
         hip.declare("dtf_bn_fwd_train_pre", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, I, L, I, I, L, P])
+        hip.declare("dtf_bn2_fwd_train", [P, P, P, P, P, P, P, P, I, P, P, P, P, Fl, Fl, Fl, Fl, P, P, P, L, I, P])
+        hip.declare("dtf_bn2_bwd_train", [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, I, P])
         hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, P, L, I, I, P])
         hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, L, L, P])
         _declared = True
@@ -179,6 +181,77 @@ class _FusedBNAct(torch.autograd.Function):
             int(ctx.relu_mode), 0, ctx.ldx, lddx, hip.stream())
         hip.check(rc, "dtf_bn_bwd_train")
         return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None
+
+
+_BN2 = __import__("os").environ.get("DTF_BN2", "1") != "0"      # A/B switch for fused_bn2_add_relu
+
+
+class _FusedBN2AddReLU(torch.autograd.Function):
+    """``relu(BN_a(xa) + BN_b(xb))`` in one node (first block of a ResNet stage: expand conv + shortcut conv): no
+    intermediate shortcut tensor forward, no masked-gradient tensor backward -- 6 activation-sized HBM passes fewer
+    than ``bn_a(xa, residual=bn_b(xb))`` (kernels ``bn2_*`` in ``bn_kernels.hip``)."""
+
+    @staticmethod
+    def forward(ctx, xa, wa, ba, rma, rva, xb, wb, bb, rmb, rvb, mom_a, eps_a, mom_b, eps_b):
+        lib = _lib()
+        M, C = _nhwc_rows(xa)
+        dev = xa.device
+        y = torch.empty_like(xa)
+        stats = torch.empty(2, 4, C, dtype=torch.float32, device=dev)
+        mask = torch.empty(int(lib.dtf_bn_mask_bytes(M, C)), dtype=torch.uint8, device=dev)
+        part = _partial2(dev, M, C)
+        rc = lib.dtf_bn2_fwd_train(hip.ptr(xa), hip.ptr(xb), hip.ptr(y), hip.ptr(mask), hip.ptr(wa), hip.ptr(ba), hip.ptr(wb),
+                                   hip.ptr(bb), hip.dt(wa), hip.ptr(rma), hip.ptr(rva), hip.ptr(rmb), hip.ptr(rvb),
+                                   float(mom_a), float(eps_a), float(mom_b), float(eps_b), stats[0].data_ptr(),
+                                   stats[1].data_ptr(), hip.ptr(part), M, C, hip.stream())
+        hip.check(rc, "dtf_bn2_fwd_train")
+        ctx.save_for_backward(xa, xb, mask, wa, wb, stats)
+        ctx.dims = (M, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xa, xb, mask, wa, wb, stats = ctx.saved_tensors
+        M, C = ctx.dims
+        lib = _lib()
+        dev = xa.device
+        if _nhwc_rows(dy) is None:
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dxa, dxb = torch.empty_like(xa), torch.empty_like(xb)
+        dgb = torch.empty(2, 2, C, dtype=wa.dtype, device=dev)
+        coef = torch.empty(2, 3, C, dtype=torch.float32, device=dev)
+        rc = lib.dtf_bn2_bwd_train(hip.ptr(dy), hip.ptr(xa), hip.ptr(xb), hip.ptr(mask), hip.ptr(wa), hip.ptr(wb), hip.dt(wa),
+                                   stats[0].data_ptr(), stats[1].data_ptr(), hip.ptr(dxa), hip.ptr(dxb), dgb[0].data_ptr(),
+                                   dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial2(dev, M, C)), M, C, hip.stream())
+        hip.check(rc, "dtf_bn2_bwd_train")
+        return dxa, dgb[0, 0], dgb[0, 1], None, None, dxb, dgb[1, 0], dgb[1, 1], None, None, None, None, None, None
+
+
+_partial2_ws = {}
+
+
+def _partial2(device, M, C):
+    need = 2 * int(_lib().dtf_bn_partial_floats(M, C))
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _partial2_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 17), dtype=torch.float32, device=device)
+        _partial2_ws[key] = ws
+    return ws
+
+
+def fused_bn2_add_relu(xa, bn_a, xb, bn_b):
+    """``relu(bn_a(xa) + bn_b(xb))`` for two :class:`FusedBatchNormAct` layers, ``bn_a`` being the one that owns the
+    add + ReLU (``relu=True``) and ``bn_b`` the plain one (``relu=False``)."""
+    ok = (_BN2 and bn_a.training and bn_b.training and bn_a.relu and not bn_b.relu and torch.is_grad_enabled()
+          and xa.shape == xb.shape and xa.dim() == 4 and xa.dtype == xb.dtype
+          and kernel_eligible(xa, bn_a.weight) and kernel_eligible(xb, bn_b.weight)
+          and _nhwc_rows(xa) is not None and _nhwc_rows(xb) is not None and bn_a.weight.dtype == bn_b.weight.dtype)
+    if not ok:
+        return bn_a(xa, bn_b(xb))
+    return _FusedBN2AddReLU.apply(xa, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var,
+                                  xb, bn_b.weight, bn_b.bias, bn_b.running_mean, bn_b.running_var,
+                                  bn_a.momentum, bn_a.eps, bn_b.momentum, bn_b.eps)
 
 
 class _BNConcat(torch.autograd.Function):

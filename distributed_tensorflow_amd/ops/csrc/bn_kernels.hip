@@ -359,6 +359,203 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
 }
 
 // ---------------------------------------------------------------------------
+// Two BatchNorms feeding one add + ReLU: the first block of every ResNet stage,
+//   out = relu( BN_a(conv3 output) + BN_b(shortcut conv output) ).
+// As two layers that is: BN_b apply (write sc), BN_a apply with residual (read sc); backward: BN_a writes the
+// masked gradient for the shortcut (dres), BN_b's reduce and apply passes read it back.  One node instead moves
+// every tensor once per pass: forward apply reads xa, xb and writes out (+ mask); backward reduce reads dy, xa, xb;
+// backward apply reads dy, xa, xb and writes dxa, dxb -- 6 activation-sized passes fewer per block.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn2_fwd_apply_kernel(const unsigned short* __restrict__ xa,
+                                                            const unsigned short* __restrict__ xb,
+                                                            const float* __restrict__ scale_a, const float* __restrict__ shift_a,
+                                                            const float* __restrict__ scale_b, const float* __restrict__ shift_b,
+                                                            unsigned short* __restrict__ y, unsigned char* __restrict__ mask,
+                                                            int64_t M, int C, int rows_per_block) {
+    const int tx = threadIdx.x & 7;
+    const int ty = threadIdx.x >> 3;
+    const int c0 = blockIdx.y * BN_CT + tx * 8;
+    if (c0 >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float sa[8], ha[8], sb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sa[k] = scale_a[c0 + k];
+        sb[k] = scale_b[c0 + k];
+        ha[k] = shift_a[c0 + k] + shift_b[c0 + k];
+    }
+    unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
+    for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+        float av[BN_UNROLL][8], bv[BN_UNROLL][8];
+        bool ok[BN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            const int64_t row = r + (int64_t)u * BN_ROWS;
+            ok[u] = row < r1;
+            if (ok[u]) {
+                ld8bf(xa + row * C + c0, av[u]);
+                ld8bf(xb + row * C + c0, bv[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+            if (!ok[u]) continue;
+            const int64_t row = r + (int64_t)u * BN_ROWS;
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float o = fmaf(av[u][k], sa[k], fmaf(bv[u][k], sb[k], ha[k]));
+                m |= (o > 0.f ? 1u : 0u) << k;
+                av[u][k] = fmaxf(o, 0.f);
+            }
+            st8bf(y + row * C + c0, av[u]);
+            mrow[row * 8] = (unsigned char)m;
+        }
+    }
+}
+
+// partial_a / partial_b [(blockIdx.x * 2 + stat) * C + c]: stat 0 = sum dy', stat 1 = sum dy' * (x - mean)
+__global__ __launch_bounds__(256) void bn2_bwd_reduce_kernel(const unsigned short* __restrict__ dy,
+                                                             const unsigned short* __restrict__ xa,
+                                                             const unsigned short* __restrict__ xb,
+                                                             const unsigned char* __restrict__ mask,
+                                                             const float* __restrict__ mean_a, const float* __restrict__ mean_b,
+                                                             float* __restrict__ partial_a, float* __restrict__ partial_b,
+                                                             int64_t M, int C, int rows_per_block) {
+    const int tx = threadIdx.x & 7;
+    const int ty = threadIdx.x >> 3;
+    const int c0 = blockIdx.y * BN_CT + tx * 8;
+    const bool cvalid = c0 < C;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s1[8], s2a[8], s2b[8], ma[8], mb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2a[k] = 0.f; s2b[k] = 0.f; ma[k] = 0.f; mb[k] = 0.f; }
+    if (cvalid) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ma[k] = mean_a[c0 + k]; mb[k] = mean_b[c0 + k]; }
+        const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
+        for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+            float av[BN_UNROLL][8], bv[BN_UNROLL][8], dv[BN_UNROLL][8];
+            unsigned mk[BN_UNROLL];
+            bool ok[BN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                const int64_t row = r + (int64_t)u * BN_ROWS;
+                ok[u] = row < r1;
+                if (ok[u]) {
+                    ld8bf(dy + row * C + c0, dv[u]);
+                    ld8bf(xa + row * C + c0, av[u]);
+                    ld8bf(xb + row * C + c0, bv[u]);
+                    mk[u] = mrow[row * 8];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+                if (!ok[u]) continue;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float d = ((mk[u] >> k) & 1u) ? dv[u][k] : 0.f;
+                    s1[k] += d;
+                    s2a[k] = fmaf(d, av[u][k] - ma[k], s2a[k]);
+                    s2b[k] = fmaf(d, bv[u][k] - mb[k], s2b[k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            s1[k] += __shfl_xor(s1[k], o, 64);
+            s2a[k] += __shfl_xor(s2a[k], o, 64);
+            s2b[k] += __shfl_xor(s2b[k], o, 64);
+        }
+    }
+    __shared__ float red[4][3][BN_CT];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            red[wave][0][lane * 8 + k] = s1[k];
+            red[wave][1][lane * 8 + k] = s2a[k];
+            red[wave][2][lane * 8 + k] = s2b[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * BN_CT) {
+        const int stat = threadIdx.x / BN_CT, cc = threadIdx.x % BN_CT;
+        const int c = blockIdx.y * BN_CT + cc;
+        if (c < C) {
+            const float v = red[0][stat][cc] + red[1][stat][cc] + red[2][stat][cc] + red[3][stat][cc];
+            if (stat == 0) {
+                partial_a[((int64_t)blockIdx.x * 2 + 0) * C + c] = v;
+                partial_b[((int64_t)blockIdx.x * 2 + 0) * C + c] = v;
+            } else if (stat == 1) {
+                partial_a[((int64_t)blockIdx.x * 2 + 1) * C + c] = v;
+            } else {
+                partial_b[((int64_t)blockIdx.x * 2 + 1) * C + c] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const unsigned short* __restrict__ dy,
+                                                            const unsigned short* __restrict__ xa,
+                                                            const unsigned short* __restrict__ xb,
+                                                            const unsigned char* __restrict__ mask,
+                                                            const float* __restrict__ coef_a, const float* __restrict__ coef_b,
+                                                            unsigned short* __restrict__ dxa, unsigned short* __restrict__ dxb,
+                                                            int64_t M, int C, int rows_per_block) {
+    const int tx = threadIdx.x & 7;
+    const int ty = threadIdx.x >> 3;
+    const int c0 = blockIdx.y * BN_CT + tx * 8;
+    if (c0 >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float a1[8], a2[8], a3[8], b1[8], b2[8], b3[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a1[k] = coef_a[c0 + k]; a2[k] = coef_a[C + c0 + k]; a3[k] = coef_a[2 * C + c0 + k];
+        b1[k] = coef_b[c0 + k]; b2[k] = coef_b[C + c0 + k]; b3[k] = coef_b[2 * C + c0 + k];
+    }
+    const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
+    for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * 2) {
+        float av[2][8], bv[2][8], dv[2][8];
+        unsigned mk[2];
+        bool ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t row = r + (int64_t)u * BN_ROWS;
+            ok[u] = row < r1;
+            if (ok[u]) {
+                ld8bf(dy + row * C + c0, dv[u]);
+                ld8bf(xa + row * C + c0, av[u]);
+                ld8bf(xb + row * C + c0, bv[u]);
+                mk[u] = mrow[row * 8];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!ok[u]) continue;
+            const int64_t row = r + (int64_t)u * BN_ROWS;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float d = ((mk[u] >> k) & 1u) ? dv[u][k] : 0.f;
+                av[u][k] = fmaf(a1[k], d, fmaf(a2[k], av[u][k], a3[k]));
+                bv[u][k] = fmaf(b1[k], d, fmaf(b2[k], bv[u][k], b3[k]));
+            }
+            st8bf(dxa + row * C + c0, av[u]);
+            st8bf(dxb + row * C + c0, bv[u]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, int* ctiles) {
@@ -520,6 +717,76 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
     else if (relu_mode == BN_BWD_RELU_MASK) { if (dres) BWD(BN_BWD_RELU_MASK, true); else BWD(BN_BWD_RELU_MASK, false); }
     else { if (dres) BWD(BN_BWD_PLAIN, true); else BWD(BN_BWD_PLAIN, false); }
 #undef BWD
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// relu( BN_a(xa) + BN_b(xb) ), training mode.  stats_a / stats_b: fp32 [4][C] = mean, invstd, scale, shift (outputs);
+// partial: workspace of 2 * dtf_bn_partial_floats(M, C) floats; mask: dtf_bn_mask_bytes(M, C)
+int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const void* gamma_a, const void* beta_a,
+                      const void* gamma_b, const void* beta_b, int param_dtype, float* rm_a, float* rv_a, float* rm_b,
+                      float* rv_b, float momentum_a, float eps_a, float momentum_b, float eps_b, float* stats_a,
+                      float* stats_b, float* partial, int64_t M, int C, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0 || !mask) return -20;
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    float* pa = partial;
+    float* pb = partial + (int64_t)nb * 2 * C;
+    const unsigned short *xas = (const unsigned short*)xa, *xbs = (const unsigned short*)xb;
+    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream, xas, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, pa, M, C, rpb, (int64_t)C, (int64_t)C);
+    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream, xbs, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, pb, M, C, rpb, (int64_t)C, (int64_t)C);
+    const float inv_count = 1.0f / (float)M;
+    const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
+#define FIN(PDT)                                                                                                              \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pa, nb, C, inv_count, unbias,    \
+                           gamma_a, beta_a, rm_a, rv_a, momentum_a, eps_a, stats_a, stats_a + C, stats_a + 2 * C,             \
+                           stats_a + 3 * C);                                                                                  \
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pb, nb, C, inv_count, unbias,    \
+                           gamma_b, beta_b, rm_b, rv_b, momentum_b, eps_b, stats_b, stats_b + C, stats_b + 2 * C,             \
+                           stats_b + 3 * C);                                                                                  \
+    } while (0)
+    if (param_dtype == DTF_BF16) FIN(DTF_BF16); else FIN(DTF_F32);
+#undef FIN
+    hipLaunchKernelGGL(bn2_fwd_apply_kernel, dim3(nb, ct), dim3(256), 0, stream, xas, xbs, stats_a + 2 * C, stats_a + 3 * C,
+                       stats_b + 2 * C, stats_b + 3 * C, (unsigned short*)y, (unsigned char*)mask, M, C, rpb);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// backward of dtf_bn2_fwd_train.  dgb_a / dgb_b: param dtype [2][C] = dgamma, dbeta; coef: fp32 [2][3][C] workspace
+int dtf_bn2_bwd_train(const void* dy, const void* xa, const void* xb, const void* mask, const void* gamma_a,
+                      const void* gamma_b, int param_dtype, const float* stats_a, const float* stats_b, void* dxa, void* dxb,
+                      void* dgb_a, void* dgb_b, float* coef, float* partial, int64_t M, int C, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0 || !mask) return -20;
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    float* pa = partial;
+    float* pb = partial + (int64_t)nb * 2 * C;
+    float* coef_a = coef;
+    float* coef_b = coef + 3 * (int64_t)C;
+    const unsigned short *dys = (const unsigned short*)dy, *xas = (const unsigned short*)xa, *xbs = (const unsigned short*)xb;
+    hipLaunchKernelGGL(bn2_bwd_reduce_kernel, dim3(nb, ct), dim3(256), 0, stream, dys, xas, xbs, (const unsigned char*)mask,
+                       stats_a, stats_b, pa, pb, M, C, rpb);
+    const float inv_count = 1.0f / (float)M;
+    const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
+    const int esz = param_dtype == DTF_BF16 ? 2 : 4;
+#define FIN(PDT)                                                                                                              \
+    do {                                                                                                                      \
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pa, nb, C, inv_count, gamma_a,    \
+                           stats_a, stats_a + C, dgb_a, (void*)((char*)dgb_a + (int64_t)C * esz), coef_a);                    \
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pb, nb, C, inv_count, gamma_b,    \
+                           stats_b, stats_b + C, dgb_b, (void*)((char*)dgb_b + (int64_t)C * esz), coef_b);                    \
+    } while (0)
+    if (param_dtype == DTF_BF16) FIN(DTF_BF16); else FIN(DTF_F32);
+#undef FIN
+    hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(nb, ct), dim3(256), 0, stream, dys, xas, xbs, (const unsigned char*)mask, coef_a,
+                       coef_b, (unsigned short*)dxa, (unsigned short*)dxb, M, C, rpb);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -1052,3 +1052,52 @@ def test_batchnorm_reads_a_channel_slice_in_place(dev, with_res):
         outs.append((y.detach().clone(), p.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_var.clone()))
     for t1, t2 in zip(*outs):
         assert torch.equal(t1, t2)
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 14, 14), (3, 72, 9, 11), (2, 2048, 7, 7)])
+def test_dual_batchnorm_add_relu_matches_reference(dev, shape, monkeypatch):
+    """relu(BN_a(xa) + BN_b(xb)) as one node: against the fp32 framework graph (values, all gradients, moving
+    statistics) and against the two-layer K7 form ``bn_a(xa, residual=bn_b(xb))`` (which rounds the shortcut to bf16
+    first, so a few ReLU decisions at the knife edge differ)."""
+    import torch.nn.functional as F
+
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod
+
+    torch.manual_seed(0)
+    C = shape[1]
+    xa = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xb = (torch.randn(shape, device=dev) * 2 + 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(bnmod, "_BN2", fused)
+        bna = bnmod.FusedBatchNormAct(C, relu=True).to(dev).to(torch.bfloat16).train()
+        bnb = bnmod.FusedBatchNormAct(C, relu=False).to(dev).to(torch.bfloat16).train()
+        torch.manual_seed(1)
+        with torch.no_grad():
+            for m in (bna, bnb):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.5, 0.5)
+        a, b = xa.clone().requires_grad_(), xb.clone().requires_grad_()
+        y = bnmod.fused_bn2_add_relu(a, bna, b, bnb)
+        assert (type(y.grad_fn).__name__.startswith("_FusedBN2")) == fused
+        y.backward(dy)
+        outs.append([y.detach().float(), a.grad.float(), b.grad.float(), bna.weight.grad.float(), bna.bias.grad.float(),
+                     bnb.weight.grad.float(), bnb.bias.grad.float(), bna.running_mean.clone(), bna.running_var.clone(),
+                     bnb.running_mean.clone(), bnb.running_var.clone()])
+        if fused:
+            wa, ba, wb, bb = (t.detach().float().requires_grad_() for t in (bna.weight, bna.bias, bnb.weight, bnb.bias))
+    f, r = outs
+    # fp32 reference of the same function
+    a32, b32 = xa.float().requires_grad_(), xb.float().requires_grad_()
+    y32 = F.relu(F.batch_norm(a32, None, None, wa, ba, True, 0.1, 1e-5) + F.batch_norm(b32, None, None, wb, bb, True, 0.1, 1e-5))
+    y32.backward(dy.float())
+    torch.testing.assert_close(f[0], y32.detach(), rtol=1e-2, atol=2e-2)
+    for got, ref in ((f[1], a32.grad), (f[2], b32.grad), (f[3], wa.grad), (f[4], ba.grad), (f[5], wb.grad), (f[6], bb.grad)):
+        assert float((got - ref).norm() / (ref.norm() + 1e-6)) < 1.5e-2
+    # two-layer K7 form
+    torch.testing.assert_close(f[0], r[0], rtol=2e-2, atol=3e-2)
+    for i in (1, 2, 3, 4, 5, 6):
+        assert float((f[i] - r[i]).norm() / (r[i].norm() + 1e-6)) < 6e-2, i
+    for i in (7, 8, 9, 10):
+        assert torch.equal(f[i], r[i])          # statistics come from the same kernels
