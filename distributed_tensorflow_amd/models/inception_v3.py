@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct, GradSlices, bn_act_concat
 from ..ops.conv import Conv1x1, Conv2dTN, conv1x1
-from ..ops.pool import avg_pool2d, max_pool2d
+from ..ops.pool import avg_pool2d, bn_relu_max_pool2d, max_pool2d
 
 
 class ConvBN(nn.Module):
@@ -286,10 +286,11 @@ class InceptionV3(nn.Module):
                 nn.init.trunc_normal_(m.weight, std=0.1, a=-0.2, b=0.2)
 
     def forward(self, x):
-        x = self.Conv2d_2b_3x3(self.Conv2d_2a_3x3(self.Conv2d_1a_3x3(x)))
-        x = max_pool2d(x, 3, 2)
-        x = self.Conv2d_4a_3x3(self.Conv2d_3b_1x1(x))
-        x = max_pool2d(x, 3, 2)
+        # the BatchNorm + ReLU in front of each stem pool runs inside the pooling kernel (ops/pool.py)
+        x = self.Conv2d_2a_3x3(self.Conv2d_1a_3x3(x))
+        x = bn_relu_max_pool2d(self.Conv2d_2b_3x3.conv(x), self.Conv2d_2b_3x3.bn, 3, 2)
+        x = self.Conv2d_3b_1x1(x)
+        x = bn_relu_max_pool2d(self.Conv2d_4a_3x3.conv(x), self.Conv2d_4a_3x3.bn, 3, 2)
         x = self.Mixed_5d(self.Mixed_5c(self.Mixed_5b(x)))
         x = self.Mixed_6e(self.Mixed_6d(self.Mixed_6c(self.Mixed_6b(self.Mixed_6a(x)))))
         aux = self.AuxLogits(x) if (self.AuxLogits is not None and self.training) else None

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct, fused_bn2_add_relu
 from ..ops.conv import Conv1x1, Conv2dTN
-from ..ops.pool import max_pool2d
+from ..ops.pool import bn_relu_max_pool2d
 
 _DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
@@ -104,8 +104,8 @@ class ResNet(nn.Module):
                     nn.init.zeros_(m.bn3.weight)
 
     def forward(self, x):
-        x = self.bn1(self.conv1(x))
-        x = max_pool2d(x, 3, 2, 1)           # K9: tap-index forward, gather backward
+        # BatchNorm + ReLU applied inside the pooling kernel: the normalised 112x112 tensor is never materialised
+        x = bn_relu_max_pool2d(self.conv1(x), self.bn1, 3, 2, 1)
         x = self.block4(self.block3(self.block2(self.block1(x))))
         x = x.mean((2, 3))
         return self.fc(x)

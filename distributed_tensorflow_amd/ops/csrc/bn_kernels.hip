@@ -640,6 +640,29 @@ int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const 
     return 0;
 }
 
+// Statistics + finalize only (the apply pass is fused into the consumer: ops/pool.py bn_relu_max_pool2d)
+int dtf_bn_stats_train(const void* x, const void* gamma, const void* beta, int param_dtype, float* running_mean,
+                       float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                       float* partial, int64_t M, int C, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0) return -20;
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream, (const unsigned short*)x, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, partial, M, C, rpb, (int64_t)C, (int64_t)C);
+    const float inv_count = 1.0f / (float)M;
+    const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
+    if (param_dtype == DTF_BF16)
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C, inv_count,
+                           unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    else
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C, inv_count,
+                           unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
 // Training forward with the statistics partials already computed by the producer of x (K6 STATS epilogue):
 // partial = fp32 [nblk][2][C] column sums / sums of squares; finalize + apply only.
 int dtf_bn_fwd_train_pre(const void* x, const void* res, void* y, void* mask, const void* gamma, const void* beta,

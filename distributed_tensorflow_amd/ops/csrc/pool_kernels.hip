@@ -10,8 +10,12 @@
 //             of x: 656 us vs ~150 us for the 112x112x64 stem pool at batch 256).
 #include "dtf_common.h"
 
-template <int K>
+// AFFINE: the input is a convolution output whose training-mode BatchNorm + ReLU has not been applied yet: every tap
+// is mapped through relu(x * scale[c] + shift[c]) (rounded to bf16 like the K7 apply pass would store it) on the
+// way in, so the normalised full-resolution tensor -- 2.8x the pool output at 3x3/2 -- is never written or read.
+template <int K, bool AFFINE>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* __restrict__ x,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                           unsigned short* __restrict__ y,
                                                           unsigned char* __restrict__ tap, int N, int H, int W,
                                                           int C, int OH, int OW, int stride, int pad) {
@@ -31,6 +35,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
 #pragma unroll
         for (int k = 0; k < 8; ++k) { best[k] = -INFINITY; bi[k] = kh0 * K + kw0; }
         const unsigned short* xn = x + (int64_t)n * H * W * C + c8 * 8;
+        float sc[8], sh[8];
+        if (AFFINE) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { sc[k] = scale[c8 * 8 + k]; sh[k] = shift[c8 * 8 + k]; }
+        }
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
             const int h = h0 + kh;
@@ -41,6 +50,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
                 if (w < 0 || w >= W) continue;
                 float v[8];
                 load8<DTF_BF16>(xn, ((int64_t)h * W + w) * C, v);
+                if (AFFINE) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f)));
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const bool take = (v[k] > best[k]) || (v[k] != v[k]);
@@ -212,9 +225,32 @@ int dtf_maxpool_fwd(const void* x, void* y, void* tap, int N, int H, int W, int 
     unsigned short* ys = (unsigned short*)y;
     unsigned char* ts = (unsigned char*)tap;
     if (k == 3)
-        hipLaunchKernelGGL((maxpool_fwd_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, stream, xs, ys, ts, N, H, W, C, OH, OW, stride, pad);
+        hipLaunchKernelGGL((maxpool_fwd_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, stream, xs, nullptr, nullptr, ys, ts, N, H, W, C, OH, OW, stride, pad);
     else if (k == 2)
-        hipLaunchKernelGGL((maxpool_fwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, xs, ys, ts, N, H, W, C, OH, OW, stride, pad);
+        hipLaunchKernelGGL((maxpool_fwd_kernel<2, false>), dim3((unsigned)blocks), dim3(256), 0, stream, xs, nullptr, nullptr, ys, ts, N, H, W, C, OH, OW, stride, pad);
+    else
+        return -23;
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// max_pool( relu(x * scale[c] + shift[c]) ): x is the raw convolution output, scale / shift the fp32 [C] vectors of
+// its BatchNorm (see maxpool_fwd_kernel AFFINE)
+int dtf_maxpool_fwd_affine(const void* x, const float* scale, const float* shift, void* y, void* tap, int N, int H, int W,
+                           int C, int OH, int OW, int k, int stride, int pad, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || N <= 0 || OH <= 0 || OW <= 0 || stride < 1 || pad < 0 || pad >= k || !scale || !shift) return -20;
+    if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return -21;
+    const int64_t items = (int64_t)N * OH * OW * (C / 8);
+    int64_t blocks = (items + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    const unsigned short* xs = (const unsigned short*)x;
+    unsigned short* ys = (unsigned short*)y;
+    unsigned char* ts = (unsigned char*)tap;
+    if (k == 3)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<3, true>), dim3((unsigned)blocks), dim3(256), 0, stream, xs, scale, shift, ys, ts, N, H, W, C, OH, OW, stride, pad);
+    else if (k == 2)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<2, true>), dim3((unsigned)blocks), dim3(256), 0, stream, xs, scale, shift, ys, ts, N, H, W, C, OH, OW, stride, pad);
     else
         return -23;
     DTF_CHECK_LAUNCH();

@@ -28,6 +28,7 @@ def _lib():
         hip.declare("dtf_maxpool_fwd", [P, P, P, I, I, I, I, I, I, I, I, I, P])
         hip.declare("dtf_maxpool_bwd", [P, P, P, I, I, I, I, I, I, I, I, I, P])
         hip.declare("dtf_avgpool", [P, P, I, I, I, I, I, I, I, I, I, I, I, P])
+        hip.declare("dtf_maxpool_fwd_affine", [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P])
         _declared = True
     return lib
 
@@ -68,6 +69,82 @@ def max_pool2d(x, kernel_size, stride=None, padding=0):
             and x.shape[3] + 2 * padding >= kernel_size):
         return _MaxPoolNHWC.apply(x, int(kernel_size), int(stride), int(padding))
     return F.max_pool2d(x, kernel_size, stride, padding)
+
+
+_BN_POOL = os.environ.get("DTF_BN_POOL", "1") != "0"      # A/B switch for bn_relu_max_pool2d
+
+
+class _BNReLUMaxPool(torch.autograd.Function):
+    """``max_pool2d(relu(batch_norm(x)))`` in training mode without the normalised full-resolution tensor: the K7
+    statistics pass + finalize, then the K9 pooling kernel applies ``relu(x * scale + shift)`` to every tap on the way
+    in.  Backward: K9 gather -> gradient w.r.t. the (virtual) BatchNorm output, then the ordinary K7 backward, which
+    recomputes the ReLU mask from ``x`` anyway."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, k, stride, pad):
+        from . import batchnorm as bnmod
+
+        lib = _lib()
+        bl = bnmod._lib()
+        if not getattr(_BNReLUMaxPool, "_declared", False):
+            P, I, L, Fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+            hip.declare("dtf_bn_stats_train", [P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, L, I, P])
+            _BNReLUMaxPool._declared = True
+        N, C, H, W = x.shape
+        M = N * H * W
+        dev = x.device
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)
+        rc = bl.dtf_bn_stats_train(hip.ptr(x), hip.ptr(weight), hip.ptr(bias), hip.dt(weight), hip.ptr(running_mean),
+                                   hip.ptr(running_var), float(momentum), float(eps), stats[0].data_ptr(), stats[1].data_ptr(),
+                                   stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(bnmod._partial(dev, M, C)), M, C,
+                                   hip.stream())
+        hip.check(rc, "dtf_bn_stats_train")
+        OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        tap = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=dev)
+        rc = lib.dtf_maxpool_fwd_affine(hip.ptr(x), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(y), hip.ptr(tap), N, H, W,
+                                        C, OH, OW, k, stride, pad, hip.stream())
+        hip.check(rc, "dtf_maxpool_fwd_affine")
+        ctx.save_for_backward(x, tap, weight, stats)
+        ctx.geom = (N, C, H, W, OH, OW, k, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import batchnorm as bnmod
+
+        x, tap, weight, stats = ctx.saved_tensors
+        N, C, H, W, OH, OW, k, stride, pad = ctx.geom
+        dev = x.device
+        if not dy.is_contiguous(memory_format=torch.channels_last):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dbn = torch.empty((N, C, H, W), dtype=dy.dtype, device=dev, memory_format=torch.channels_last)
+        rc = _lib().dtf_maxpool_bwd(hip.ptr(dy), hip.ptr(tap), hip.ptr(dbn), N, H, W, C, OH, OW, k, stride, pad, hip.stream())
+        hip.check(rc, "dtf_maxpool_bwd")
+        M = N * H * W
+        dx = torch.empty_like(dbn)
+        dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
+        coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+        rc = bnmod._lib().dtf_bn_bwd_train(
+            hip.ptr(dbn), hip.ptr(x), None, hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(), stats[1].data_ptr(),
+            stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), None, dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef),
+            hip.ptr(bnmod._partial(dev, M, C)), M, C, 1, 0, 0, 0, hip.stream())
+        hip.check(rc, "dtf_bn_bwd_train (pool)")
+        return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
+
+
+def bn_relu_max_pool2d(x, bn, kernel_size, stride=None, padding=0):
+    """``max_pool2d(bn(x), ...)`` for a :class:`~.batchnorm.FusedBatchNormAct` with ``relu=True``."""
+    from . import batchnorm as bnmod
+
+    stride = kernel_size if stride is None else stride
+    if (_BN_POOL and _ENABLED and bn.training and bn.relu and torch.is_grad_enabled() and x.dim() == 4
+            and bnmod.kernel_eligible(x, bn.weight) and x.is_contiguous(memory_format=torch.channels_last)
+            and kernel_size in (2, 3) and 0 <= padding < kernel_size and x.shape[2] + 2 * padding >= kernel_size
+            and x.shape[3] + 2 * padding >= kernel_size):
+        return _BNReLUMaxPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                    int(kernel_size), int(stride), int(padding))
+    return max_pool2d(bn(x), kernel_size, stride, padding)
 
 
 class _AvgPoolNHWC(torch.autograd.Function):

@@ -1101,3 +1101,30 @@ def test_dual_batchnorm_add_relu_matches_reference(dev, shape, monkeypatch):
         assert float((f[i] - r[i]).norm() / (r[i].norm() + 1e-6)) < 6e-2, i
     for i in (7, 8, 9, 10):
         assert torch.equal(f[i], r[i])          # statistics come from the same kernels
+
+
+@pytest.mark.parametrize("shape,k,s,p", [((4, 64, 30, 30), 3, 2, 1), ((3, 64, 29, 31), 3, 2, 0), ((2, 192, 17, 17), 3, 2, 0)])
+def test_bn_relu_maxpool_matches_two_ops(dev, shape, k, s, p, monkeypatch):
+    """BatchNorm + ReLU applied inside the pooling kernel against K7 followed by K9: same values and gradients."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, pool
+
+    torch.manual_seed(0)
+    x0 = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(pool, "_BN_POOL", fused)
+        bn = bnmod.FusedBatchNormAct(shape[1], relu=True).to(dev).to(torch.bfloat16).train()
+        torch.manual_seed(1)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.5, 0.5)
+        x = x0.clone().requires_grad_()
+        y = pool.bn_relu_max_pool2d(x, bn, k, s, p)
+        assert ("BNReLUMaxPool" in type(y.grad_fn).__name__) == fused
+        dy = torch.linspace(-1, 1, y.numel(), device=dev).view(y.shape).to(y.dtype).contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        outs.append([y.detach().clone(), x.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(),
+                     bn.running_var.clone()])
+    f, r = outs
+    for a, b in zip(f, r):
+        assert torch.equal(a, b)
