@@ -51,10 +51,55 @@ __device__ __forceinline__ void st8bf(unsigned short* p, const float (&v)[8]) {
     *reinterpret_cast<u32x4*>(p) = r;
 }
 
+// POOL variants of the backward kernels: the layer's output went straight into a max pool (ops/pool.py
+// bn_relu_max_pool2d), so its gradient is not a tensor but the pool's gather over the windows covering each pixel
+// (K9's backward formulation) of the POOLED gradient + winning-tap bytes -- the full-resolution gradient is never
+// written or read.  Same arithmetic as maxpool_bwd_kernel, including the bf16 rounding of the per-pixel sum.
+struct PoolGeom {
+    const unsigned short* dyp; const unsigned char* tap;
+    int H, W, OH, OW, K, stride, pad;
+};
+
+__device__ __forceinline__ void pool_gather_dy(const PoolGeom& g, int64_t row, int C, int c0, float (&d)[8]) {
+    const unsigned r = (unsigned)row;
+    const int w = (int)(r % (unsigned)g.W);
+    const unsigned q = r / (unsigned)g.W;
+    const int h = (int)(q % (unsigned)g.H);
+    const int n = (int)(q / (unsigned)g.H);
+    int oh_lo = h + g.pad - (g.K - 1);
+    oh_lo = oh_lo <= 0 ? 0 : (oh_lo + g.stride - 1) / g.stride;
+    int oh_hi = (h + g.pad) / g.stride;
+    if (oh_hi > g.OH - 1) oh_hi = g.OH - 1;
+    int ow_lo = w + g.pad - (g.K - 1);
+    ow_lo = ow_lo <= 0 ? 0 : (ow_lo + g.stride - 1) / g.stride;
+    int ow_hi = (w + g.pad) / g.stride;
+    if (ow_hi > g.OW - 1) ow_hi = g.OW - 1;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+        const unsigned kh = (unsigned)(h + g.pad - oh * g.stride);
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+            const unsigned me = kh * (unsigned)g.K + (unsigned)(w + g.pad - ow * g.stride);
+            const int64_t o = (((int64_t)n * g.OH + oh) * g.OW + ow) * C + c0;
+            const u32x2 pk = *reinterpret_cast<const u32x2*>(g.tap + o);
+            float v[8];
+            ld8bf(g.dyp + o, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned b = (pk[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                acc[k] += (b == me) ? v[k] : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d[k] = bf16_to_f32(f32_to_bf16(acc[k]));
+}
+
 // partial[(blockIdx.x * 2 + stat) * C + c]
 // U = rows in flight per lane: the single-operand statistics pass needs 8 (64 B per lane is too
 // little to cover the HBM latency: 3.3 TB/s measured), the two-operand backward pass 4.
-template <int MODE, int U>
+template <int MODE, int U, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __restrict__ x,
                                                         const unsigned short* __restrict__ dy,
                                                         const unsigned char* __restrict__ mask,
@@ -62,7 +107,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         float* __restrict__ partial, int64_t M, int C,
-                                                        int rows_per_block, int64_t lddy, int64_t ldx) {
+                                                        int rows_per_block, int64_t lddy, int64_t ldx,
+                                                        PoolGeom pg = PoolGeom{}) {
     const int tx = threadIdx.x & 7;
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
@@ -93,7 +139,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                 ok[u] = row < r1;
                 if (ok[u]) {
                     ld8bf(x + row * ldx + c0, xv[u]);
-                    if (MODE != BN_FWD_STATS) ld8bf(dy + row * lddy + c0, dv[u]);
+                    if (MODE != BN_FWD_STATS) {
+                        if (POOL) pool_gather_dy(pg, row, C, c0, dv[u]);
+                        else ld8bf(dy + row * lddy + c0, dv[u]);
+                    }
                     if (MODE == BN_BWD_RELU_MASK) mb[u] = mrow[row * 8];
                 }
             }
@@ -298,7 +347,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const unsigned short*
 }
 
 // dx = k1*dy' + k2*x + k3 ; dres = dy'   (dy' = dy under the ReLU mask)
-template <int MODE, bool RES>
+template <int MODE, bool RES, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short* __restrict__ dy,
                                                            const unsigned short* __restrict__ x,
                                                            const unsigned char* __restrict__ mask,
@@ -307,7 +356,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
                                                            const float* __restrict__ coef,
                                                            unsigned short* __restrict__ dx,
                                                            unsigned short* __restrict__ dres, int64_t M, int C,
-                                                           int rows_per_block, int64_t lddy, int64_t ldx, int64_t lddx) {
+                                                           int rows_per_block, int64_t lddy, int64_t ldx, int64_t lddx,
+                                                           PoolGeom pg = PoolGeom{}) {
     const int tx = threadIdx.x & 7;
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
@@ -335,7 +385,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
             const int64_t row = r + (int64_t)u * BN_ROWS;
             ok[u] = row < r1;
             if (ok[u]) {
-                ld8bf(dy + row * lddy + c0, dv[u]);
+                if (POOL) pool_gather_dy(pg, row, C, c0, dv[u]);
+                else ld8bf(dy + row * lddy + c0, dv[u]);
                 ld8bf(x + row * ldx + c0, xv[u]);
                 if (MODE == BN_BWD_RELU_MASK) mb[u] = mrow[row * 8];
             }
@@ -740,6 +791,36 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
     else if (relu_mode == BN_BWD_RELU_MASK) { if (dres) BWD(BN_BWD_RELU_MASK, true); else BWD(BN_BWD_RELU_MASK, false); }
     else { if (dres) BWD(BN_BWD_PLAIN, true); else BWD(BN_BWD_PLAIN, false); }
 #undef BWD
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Backward of max_pool(relu(BN(x))) (ops/pool.py bn_relu_max_pool2d): dyp / tap are the POOLED gradient
+// [N, OH, OW, C] and the pool's winning-tap bytes; see PoolGeom.
+int dtf_bn_bwd_train_pool(const void* dyp, const void* tap, const void* x, const void* gamma, int param_dtype,
+                          const float* mean, const float* invstd, const float* scale, const float* shift, void* dx,
+                          void* dgamma, void* dbeta, float* coef, float* partial, int N, int H, int W, int C, int OH, int OW,
+                          int k, int stride, int pad, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    const int64_t M = (int64_t)N * H * W;
+    if (C % 8 != 0 || M <= 0 || M >= (1ll << 32) || stride < 1 || pad < 0 || pad >= k) return -20;
+    if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return -21;
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    PoolGeom pg{(const unsigned short*)dyp, (const unsigned char*)tap, H, W, OH, OW, k, stride, pad};
+    const unsigned short* xs = (const unsigned short*)x;
+    hipLaunchKernelGGL((bn_reduce_kernel<BN_BWD_RELU_X, BN_UNROLL, true>), dim3(nb, ct), dim3(256), 0, stream, xs, nullptr, nullptr,
+                       mean, scale, shift, partial, M, C, rpb, (int64_t)C, (int64_t)C, pg);
+    const float inv_count = 1.0f / (float)M;
+    const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
+    if (param_dtype == DTF_BF16)
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C, inv_count, gamma,
+                           mean, invstd, dgamma, dbeta, coef);
+    else
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C, inv_count, gamma,
+                           mean, invstd, dgamma, dbeta, coef);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<BN_BWD_RELU_X, false, true>), dim3(nb, ct), dim3(256), 0, stream, nullptr, xs, nullptr,
+                       scale, shift, coef, (unsigned short*)dx, nullptr, M, C, rpb, (int64_t)C, (int64_t)C, (int64_t)C, pg);
     DTF_CHECK_LAUNCH();
     return 0;
 }

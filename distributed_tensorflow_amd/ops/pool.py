@@ -72,6 +72,10 @@ def max_pool2d(x, kernel_size, stride=None, padding=0):
 
 
 _BN_POOL = os.environ.get("DTF_BN_POOL", "1") != "0"      # A/B switch for bn_relu_max_pool2d
+# Its backward without the full-size gradient tensor (the K7 passes gather the pool gradient themselves).  Bitwise
+# equal but measured SLOWER (ResNet-50 -0.8 %, Inception-v3 -1.7 %): the gather runs twice (reduce + apply) and its
+# index arithmetic / dependent loads take the two passes off the HBM roofline.  Off by default.
+_BN_POOL_BWD = os.environ.get("DTF_BN_POOL_BWD", "0") != "0"
 
 
 class _BNReLUMaxPool(torch.autograd.Function):
@@ -118,13 +122,25 @@ class _BNReLUMaxPool(torch.autograd.Function):
         dev = x.device
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
+        M = N * H * W
+        dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dev, memory_format=torch.channels_last)
+        dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
+        coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+        if _BN_POOL_BWD:
+            # the K7 backward passes gather the pool's gradient themselves: no full-resolution gradient tensor
+            if not getattr(_BNReLUMaxPool, "_declared_bwd", False):
+                P, I = ctypes.c_void_p, ctypes.c_int
+                hip.declare("dtf_bn_bwd_train_pool", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P])
+                _BNReLUMaxPool._declared_bwd = True
+            rc = bnmod._lib().dtf_bn_bwd_train_pool(
+                hip.ptr(dy), hip.ptr(tap), hip.ptr(x), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(), stats[1].data_ptr(),
+                stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef),
+                hip.ptr(bnmod._partial(dev, M, C)), N, H, W, C, OH, OW, k, stride, pad, hip.stream())
+            hip.check(rc, "dtf_bn_bwd_train_pool")
+            return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
         dbn = torch.empty((N, C, H, W), dtype=dy.dtype, device=dev, memory_format=torch.channels_last)
         rc = _lib().dtf_maxpool_bwd(hip.ptr(dy), hip.ptr(tap), hip.ptr(dbn), N, H, W, C, OH, OW, k, stride, pad, hip.stream())
         hip.check(rc, "dtf_maxpool_bwd")
-        M = N * H * W
-        dx = torch.empty_like(dbn)
-        dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
-        coef = torch.empty(3, C, dtype=torch.float32, device=dev)
         rc = bnmod._lib().dtf_bn_bwd_train(
             hip.ptr(dbn), hip.ptr(x), None, hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(), stats[1].data_ptr(),
             stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), None, dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef),

@@ -1104,12 +1104,15 @@ def test_dual_batchnorm_add_relu_matches_reference(dev, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("shape,k,s,p", [((4, 64, 30, 30), 3, 2, 1), ((3, 64, 29, 31), 3, 2, 0), ((2, 192, 17, 17), 3, 2, 0)])
-def test_bn_relu_maxpool_matches_two_ops(dev, shape, k, s, p, monkeypatch):
-    """BatchNorm + ReLU applied inside the pooling kernel against K7 followed by K9: same values and gradients."""
+@pytest.mark.parametrize("fused_bwd", [True, False])
+def test_bn_relu_maxpool_matches_two_ops(dev, shape, k, s, p, fused_bwd, monkeypatch):
+    """BatchNorm + ReLU applied inside the pooling kernel (and the pool's gradient gathered inside the K7 backward
+    passes) against K7 followed by K9: bitwise the same values and gradients."""
     from distributed_tensorflow_amd.ops import batchnorm as bnmod, pool
 
     torch.manual_seed(0)
     x0 = torch.randn(shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    monkeypatch.setattr(pool, "_BN_POOL_BWD", fused_bwd)
     outs = []
     for fused in (True, False):
         monkeypatch.setattr(pool, "_BN_POOL", fused)
