@@ -20,9 +20,10 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct, fused_bn2_add_relu
-from ..ops.conv import Conv1x1, Conv2dTN
+from ..ops.conv import Conv1x1, Conv2dTN, conv1x1, subsample_fork
 from ..ops.pool import bn_relu_max_pool2d
 
+_SUBSAMPLE = __import__("os").environ.get("DTF_RESNET_SUBSAMPLE", "1") != "0"      # A/B switch
 _DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
 
@@ -51,6 +52,15 @@ class Bottleneck(nn.Module):
             self.shortcut_conv = None
 
     def forward(self, x):
+        sc_stride = self.shortcut_conv.stride[0] if self.shortcut_conv is not None else 1
+        if (_SUBSAMPLE and sc_stride > 1 and self.shortcut_conv.kernel_size == (1, 1) and isinstance(self.conv1, Conv1x1)
+                and self.training and x.is_cuda and x.dtype == torch.bfloat16 and x.requires_grad
+                and x.is_contiguous(memory_format=torch.channels_last)):
+            # strided 1x1 shortcut = dense 1x1 GEMM of the subsampled input; its gradient is added on those pixels only
+            xs, x = subsample_fork(x, sc_stride)
+            s = conv1x1(xs, self.shortcut_conv.weight, mm_fwd=True)
+            y = self.bn2(self.conv2(self.bn1(self.conv1(x))))
+            return fused_bn2_add_relu(self.conv3(y), self.bn3, s, self.shortcut_bn)
         if isinstance(self.conv1, Conv1x1):
             # x feeds conv1 and the shortcut: the fork sums their two gradients inside conv1's dX GEMM.
             # The shortcut's gradient comes from the K7 residual epilogue / the shortcut conv's dgrad:

@@ -182,6 +182,34 @@ class _Conv1x1ForkFn(torch.autograd.Function):
         return dx, dw, None
 
 
+class _SubsampleFork(torch.autograd.Function):
+    """``(x[:, :, ::s, ::s] as a dense tensor, x)`` for a strided 1x1 convolution next to another consumer of ``x``
+    (the shortcut of a ResNet stage's first block).  A strided 1x1 convolution only ever sees every s-th pixel, so it
+    is the dense 1x1 GEMM of the subsampled input; its data gradient lives on those pixels only.  Backward adds it
+    there IN PLACE into the gradient that comes back through the pass-through (a fresh tensor from the other
+    consumer's data-gradient GEMM) -- instead of a library backward-data kernel writing a full-resolution, 3/4-zero
+    tensor that the other consumer's GEMM then has to read and accumulate into."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x[:, :, ::s, ::s].contiguous(memory_format=torch.channels_last), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dxs, dskip):
+        s = ctx.s
+        if dskip is None:
+            raise RuntimeError("subsample_fork: the pass-through output must take part in the loss")
+        if dxs is not None:
+            dskip[:, :, ::s, ::s].add_(dxs)
+        return dskip, None
+
+
+def subsample_fork(x, stride):
+    """-> ``(x[:, :, ::stride, ::stride]`` dense, ``x')``; route the other consumer of ``x`` through ``x'``."""
+    return _SubsampleFork.apply(x, int(stride))
+
+
 def _eligible(x, weight):
     return (_ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last) and weight.shape[2] == 1 and weight.shape[3] == 1)

@@ -1131,3 +1131,27 @@ def test_bn_relu_maxpool_matches_two_ops(dev, shape, k, s, p, fused_bwd, monkeyp
     f, r = outs
     for a, b in zip(f, r):
         assert torch.equal(a, b)
+
+
+def test_resnet_strided_block_subsample_matches_strided_conv(dev, monkeypatch):
+    """First block of a stage: shortcut as subsample + dense 1x1 GEMM (gradient added on the strided pixels in place)
+    against the strided convolution through the library."""
+    from distributed_tensorflow_amd.models import resnet
+
+    torch.manual_seed(0)
+    m = resnet.Bottleneck(256, 128, 2, True).to(device=dev, dtype=torch.bfloat16, memory_format=torch.channels_last).train()
+    x0 = torch.randn(8, 256, 12, 12, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = []
+    for sub in (False, True, False):       # first pass = warm-up
+        monkeypatch.setattr(resnet, "_SUBSAMPLE", sub)
+        m.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        y = m(x * 1.0)
+        dy = torch.linspace(-1, 1, y.numel(), device=dev).view(y.shape).to(y.dtype).contiguous(memory_format=torch.channels_last)
+        y.backward(dy)
+        res.append((y.detach().float(), x.grad.float(), {n: p.grad.float() for n, p in m.named_parameters()}))
+    (y1, g1, p1), (y2, g2, p2) = res[1:]
+    torch.testing.assert_close(y1, y2, rtol=3e-2, atol=3e-2)
+    assert float((g1 - g2).norm() / g2.norm()) < 0.03
+    for n in p1:
+        assert float((p1[n] - p2[n]).norm() / (p2[n].norm() + 1e-6)) < 0.08, n

@@ -64,3 +64,23 @@ def test_inception_pool_branch_commutes():
     a = F.conv2d(F.avg_pool2d(x, 3, 1, 1, count_include_pad=False), w)
     b = F.avg_pool2d(F.conv2d(x, w), 3, 1, 1, count_include_pad=False)
     torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+
+
+def test_subsample_fork_gradient():
+    """Strided 1x1 shortcut as subsample + dense 1x1: same values and input gradient as the strided convolution."""
+    import torch.nn.functional as F
+
+    from distributed_tensorflow_amd.ops.conv import subsample_fork
+
+    torch.manual_seed(0)
+    x1 = torch.randn(2, 6, 9, 8, requires_grad=True)
+    w = torch.randn(5, 6, 1, 1)
+    w3 = torch.randn(4, 6, 3, 3)
+    xs, xp = subsample_fork(x1 * 1.0, 2)
+    out1 = F.conv2d(xs, w).sum() + (F.conv2d(xp, w3, padding=1) ** 2).sum()
+    out1.backward()
+    x2 = x1.detach().clone().requires_grad_()
+    out2 = F.conv2d(x2, w, stride=2).sum() + (F.conv2d(x2, w3, padding=1) ** 2).sum()
+    out2.backward()
+    torch.testing.assert_close(out1, out2)
+    torch.testing.assert_close(x1.grad, x2.grad)
