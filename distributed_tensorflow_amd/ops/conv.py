@@ -32,7 +32,10 @@ def _wrw(dy, x, weight):
     """dW of a 1x1 stride-1 convolution: K6T (``dY^T . X`` with the pixels as reduction rows, no zero-fill /
     cast passes around it) for wide layers, MIOpen otherwise."""
     cout, cin = weight.shape[0], weight.shape[1]
-    if _TN_WRW and min(cin, cout) >= _TN_WRW_MIN_C:
+    # measured (scripts/wrw1x1_bench.py): K6T wins from 128 channels on both sides up to ~2.6e5 pixels (ResNet's 28x28
+    # and Inception's 17x17 / 8x8 stages), from 192 channels beyond; the 56x56 layers are HBM-bound and MIOpen's
+    if _TN_WRW and (min(cin, cout) >= _TN_WRW_MIN_C
+                    or (min(cin, cout) >= 128 and dy.shape[0] * dy.shape[2] * dy.shape[3] <= 262144)):
         from .linear import gemm_tn, gemm_tn_eligible
 
         dy2, x2 = _rows(dy), _rows(x)

@@ -287,9 +287,24 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     }
 }
 
-// n extent of the block tile: 32 * NI rows, NI in {8, 6, 4, 2}.  Cost model per reduction step: NI fragments of
-// MFMA work plus a fixed ~1.5 fragments for the B reads / staging that do not shrink with NI.
-static inline int tn_pick_ni(int N) {
+// n extent of the block tile: 32 * NI rows, NI in {8, 6, 4, 2}, from a two-term cost model (microseconds):
+//   main loop : K steps per block x rounds over the CUs x (NI + 1.5) x 0.082 -- NI fragments of MFMA work plus a fixed
+//               ~1.5 fragments for the B reads / staging that do not shrink with NI (0.78 us per step at NI = 8);
+//   slabs     : every block writes its fp32 tile and the reduce kernel reads it back: blocks x 32 NI x 256 x 4 B x 2 at
+//               ~4.5 TB/s.  With few output tiles (a 1x1 convolution's 1024 x 256 filter is 4 tiles -> 64 splits) the
+//               slabs, not the MFMAs, are most of the time, and a narrower tile halves them (measured 48 -> 37 us).
+static inline void tn_splits(int mt, int ntiles, int* splits, int* per) {
+    int s = 256 / ntiles;
+    if (s < 1) s = 1;
+    if (s > mt / 4) s = mt / 4 > 0 ? mt / 4 : 1;          // at least 4 reduction tiles per split
+    *per = (mt + s - 1) / s;
+    *splits = (mt + *per - 1) / *per;
+}
+
+// CONV: a K step costs ~1.05 us whatever NI (measured 256ch 3x3 at 14x14: NI = 8 and NI = 4 both 1.04-1.09 us per
+// step -- the im2col addressing and gather, not the MFMAs, set it), so more, narrower tiles only add steps: there NI
+// is picked to waste the fewest output rows.
+static inline int tn_pick_ni(int M, int N, int K, bool conv) {
     static int forced = -1;
     if (forced < 0) {
         const char* e = getenv("DTF_TN_NI");
@@ -298,25 +313,36 @@ static inline int tn_pick_ni(int N) {
     if (forced == 2 || forced == 4 || forced == 6 || forced == 8) return forced;
     int best = 8;
     float best_cost = 1e30f;
+    if (conv) {
+        for (int ni = 8; ni >= 2; ni -= 2) {
+            const float cost = (float)((N + 32 * ni - 1) / (32 * ni)) * ((float)ni + 1.5f);
+            if (cost < best_cost - 1e-3f) { best_cost = cost; best = ni; }
+        }
+        return best;
+    }
+    const int mt = (M + 31) / 32, ntk = (K + 255) / 256;
     for (int ni = 8; ni >= 2; ni -= 2) {
-        const float cost = (float)((N + 32 * ni - 1) / (32 * ni)) * ((float)ni + 1.5f);
-        if (cost < best_cost - 1e-3f) { best_cost = cost; best = ni; }
+        const int ntiles = ((N + 32 * ni - 1) / (32 * ni)) * ntk;
+        int splits, per;
+        tn_splits(mt, ntiles, &splits, &per);
+        const int64_t blocks = (int64_t)ntiles * splits;
+        const float rounds = (float)((blocks + 255) / 256);
+        const float frag = (float)ni + 1.5f < 5.0f ? 5.0f : (float)ni + 1.5f;      // NI = 2 is LDS-read-bound: no cheaper than NI = 4
+        const float loop = (float)per * rounds * frag * 0.082f;
+        const float slab = (float)blocks * (float)ni * (32.f * 256.f * 4.f * 2.f / 4.5e6f);
+        const float cost = loop + slab;
+        if (cost < best_cost * 0.93f) { best_cost = cost; best = ni; }
     }
     return best;
 }
 
-static inline void tn_plan(int M, int N, int K, int* ni, int* ntn, int* ntk, int* splits, int* mps) {
-    *ni = tn_pick_ni(N);
+static inline void tn_plan(int M, int N, int K, int* ni, int* ntn, int* ntk, int* splits, int* mps, bool conv = false) {
+    *ni = tn_pick_ni(M, N, K, conv);
     *ntn = (N + 32 * *ni - 1) / (32 * *ni);
     *ntk = (K + 255) / 256;
-    const int ntiles = *ntn * *ntk;
-    int s = 256 / ntiles;
-    if (s < 1) s = 1;
-    const int mt = (M + 31) / 32;                // reduction tiles
-    if (s > mt / 4) s = mt / 4 > 0 ? mt / 4 : 1; // at least 4 tiles per split
-    const int per = (mt + s - 1) / s;
+    int per;
+    tn_splits((M + 31) / 32, *ntn * *ntk, splits, &per);
     *mps = per * 32;
-    *splits = (mt + per - 1) / per;
 }
 
 // table of the CONV variant (see TnArgs); entries M .. roundup(M, 32) - 1 never pass the bounds test
@@ -399,7 +425,7 @@ int dtf_gemm_tn(const void* A, const void* B, void* C, int out_dtype, void* dbia
 // fp32 workspace (floats) for dtf_conv_wrw
 int64_t dtf_conv_wrw_workspace(int64_t M, int Cout, int Ktot) {
     int ni, ntn, ntk, splits, mps;
-    tn_plan((int)M, Cout, Ktot, &ni, &ntn, &ntk, &splits, &mps);
+    tn_plan((int)M, Cout, Ktot, &ni, &ntn, &ntk, &splits, &mps, true);
     return (int64_t)splits * Cout * Ktot;
 }
 
@@ -435,7 +461,7 @@ int dtf_conv_wrw(const void* dy, const void* x, void* dw, int out_dtype, float* 
     TnArgs a{};
     int ni;
     a.A = (const unsigned short*)dy; a.B = (const unsigned short*)x; a.slab = workspace; a.M = M; a.N = Cout; a.K = Ktot;
-    tn_plan(M, Cout, Ktot, &ni, &a.ntn, &a.ntk, &a.splits, &a.m_per_split);
+    tn_plan(M, Cout, Ktot, &ni, &a.ntn, &a.ntk, &a.splits, &a.m_per_split, true);
     a.zero = (const unsigned short*)zero;
     a.tab = (const int*)tab;
     a.Cin = Cin; a.H = H; a.W = W; a.KW = KW;
