@@ -69,6 +69,7 @@ def _pre(m, x):
 
 
 _FUSE_HEADS = os.environ.get("DTF_INCEPTION_FUSE_HEADS", "1") != "0"      # A/B switch
+_POOL_IN_PLACE = os.environ.get("DTF_INCEPTION_POOL_IN_PLACE", "1") != "0"  # A/B: K9 avg pool reads / writes the head slice in place
 _HEADS_MM = os.environ.get("DTF_INCEPTION_HEADS_MM", "0") != "0"          # fused heads forward: GEMM library (1) / MIOpen (0)
 _GRAD_IN_PLACE = os.environ.get("DTF_INCEPTION_GRAD_IN_PLACE", "1") != "0"  # A/B switch: BN dx into the shared buffer
 _SLICE_VIEWS = os.environ.get("DTF_INCEPTION_SLICE_VIEWS", "1") != "0"    # A/B switch: BN reads the head slices in place
@@ -163,7 +164,7 @@ class InceptionA(nn.Module):          # Mixed_5b/5c/5d
         self.b3 = ConvBN(i, pool, 1)
 
     def forward(self, x):
-        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3], dense=(False, False, False, True)) if _POOL_AFTER_CONV else None
+        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3], dense=(False, False, False, not _POOL_IN_PLACE)) if _POOL_AFTER_CONV else None
         if hs is not None:
             pool = avg_pool2d(hs[3], 3, 1, 1, count_include_pad=False)
             return bn_act_concat([(hs[0], self.b0.bn), _tail(self.b1, hs[1]), _tail(self.b2, hs[2]), (pool, self.b3.bn)])
@@ -196,7 +197,7 @@ class InceptionC(nn.Module):          # Mixed_6b..6e
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
-        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3], dense=(False, False, False, True)) if _POOL_AFTER_CONV else None
+        hs = _heads(x, [self.b0, self.b1[0], self.b2[0], self.b3], dense=(False, False, False, not _POOL_IN_PLACE)) if _POOL_AFTER_CONV else None
         if hs is not None:
             pool = avg_pool2d(hs[3], 3, 1, 1, count_include_pad=False)
             return bn_act_concat([(hs[0], self.b0.bn), _tail(self.b1, hs[1]), _tail(self.b2, hs[2]), (pool, self.b3.bn)])
@@ -232,7 +233,7 @@ class InceptionE(nn.Module):          # Mixed_7b/7c
         self.b3 = ConvBN(i, 192, 1)
 
     def forward(self, x):
-        hs = _heads(x, [self.b0, self.b1, self.b2[0], self.b3], dense=(False, False, False, True)) if _POOL_AFTER_CONV else None
+        hs = _heads(x, [self.b0, self.b1, self.b2[0], self.b3], dense=(False, False, False, not _POOL_IN_PLACE)) if _POOL_AFTER_CONV else None
         if hs is not None:
             y1 = self.b1.bn(hs[1])
             y2 = self.b2[1](self.b2[0].bn(hs[2]))

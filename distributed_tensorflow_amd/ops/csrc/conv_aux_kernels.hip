@@ -4,7 +4,7 @@
 // launches of ~5 and ~9 us on these <= 5 MB tensors, 49 times per Inception-v3 step; this is one.
 #include "dtf_common.h"
 
-#define FT_TILE 64
+#define FT_TILE 32      // small tiles: these tensors are tiny, the kernel is latency-bound, parallelism is what helps
 
 __global__ __launch_bounds__(256) void filter_flip_transpose_kernel(const unsigned short* __restrict__ w,
                                                                     unsigned short* __restrict__ out, int Cout, int Cin,
@@ -12,16 +12,16 @@ __global__ __launch_bounds__(256) void filter_flip_transpose_kernel(const unsign
     __shared__ unsigned short tile[FT_TILE][FT_TILE + 2];
     const int t = blockIdx.z;
     const int ci0 = blockIdx.x * FT_TILE, co0 = blockIdx.y * FT_TILE;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll 4
-    for (int r = ty; r < FT_TILE; r += 4) {
+    for (int r = ty; r < FT_TILE; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         if (co < Cout && ci < Cin) tile[r][tx] = w[((int64_t)co * T + t) * Cin + ci];
     }
     __syncthreads();
     const int to = T - 1 - t;
 #pragma unroll 4
-    for (int r = ty; r < FT_TILE; r += 4) {
+    for (int r = ty; r < FT_TILE; r += 8) {
         const int ci = ci0 + r, co = co0 + tx;
         if (ci < Cin && co < Cout) out[((int64_t)ci * T + to) * Cout + co] = tile[tx][r];
     }

@@ -139,7 +139,8 @@ __device__ __forceinline__ float avg_divisor(int oh, int ow, int H, int W, int s
 template <int K>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* __restrict__ x,
                                                           unsigned short* __restrict__ y, int N, int H, int W, int C,
-                                                          int OH, int OW, int stride, int pad, int include_pad) {
+                                                          int OH, int OW, int stride, int pad, int include_pad, int64_t ld) {
+    // ld: pixel stride (elements) of x -- C, or the parent's channel count for a channel slice read in place
     const int C8 = C >> 3;
     const int64_t total = (int64_t)N * OH * OW * C8;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* 
         float acc[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-        const unsigned short* xn = x + (int64_t)n * H * W * C + c8 * 8;
+        const unsigned short* xn = x + (int64_t)n * H * W * ld + c8 * 8;
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
             const int h = h0 + kh;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* 
                 const int w = w0 + kw;
                 if (w < 0 || w >= W) continue;
                 float v[8];
-                load8<DTF_BF16>(xn, ((int64_t)h * W + w) * C, v);
+                load8<DTF_BF16>(xn, ((int64_t)h * W + w) * ld, v);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] += v[k];
             }
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const unsigned short* 
 template <int K>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const unsigned short* __restrict__ dy,
                                                           unsigned short* __restrict__ dx, int N, int H, int W, int C,
-                                                          int OH, int OW, int stride, int pad, int include_pad) {
+                                                          int OH, int OW, int stride, int pad, int include_pad, int64_t ld) {
+    // ld: pixel stride of dx (written into a channel slice of a wider gradient tensor when > C)
     const int C8 = C >> 3;
     const int64_t total = (int64_t)N * H * W * C8;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const unsigned short* 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) acc[k] = fmaf(g[k], inv, acc[k]);
             }
-        store8<DTF_BF16>(dx, ((((int64_t)n * H + h) * W + w) * C) + c8 * 8, acc);
+        store8<DTF_BF16>(dx, ((((int64_t)n * H + h) * W + w) * ld) + c8 * 8, acc);
     }
 }
 
@@ -278,9 +280,12 @@ int dtf_maxpool_bwd(const void* dy, const void* tap, void* dx, int N, int H, int
     return 0;
 }
 
+// ld: pixel stride of the full-resolution side (x forward, dx backward); 0 = C
 int dtf_avgpool(const void* in, void* out, int backward, int N, int H, int W, int C, int OH, int OW, int k, int stride,
-                int pad, int include_pad, hipStream_t stream) {
+                int pad, int include_pad, int64_t ld, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
+    if (ld == 0) ld = C;
+    if (ld < C || (ld & 7)) return -24;
     if (C % 8 != 0 || N <= 0 || OH <= 0 || OW <= 0 || stride < 1 || pad < 0 || pad >= k) return -20;
     if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return -21;
     const int64_t items = (int64_t)N * (backward ? (int64_t)H * W : (int64_t)OH * OW) * (C / 8);
@@ -292,10 +297,10 @@ int dtf_avgpool(const void* in, void* out, int backward, int N, int H, int W, in
     do {                                                                                                          \
         if (backward)                                                                                             \
             hipLaunchKernelGGL((avgpool_bwd_kernel<KK>), dim3((unsigned)blocks), dim3(256), 0, stream, is, os, N, \
-                               H, W, C, OH, OW, stride, pad, include_pad);                                        \
+                               H, W, C, OH, OW, stride, pad, include_pad, ld);                                    \
         else                                                                                                      \
             hipLaunchKernelGGL((avgpool_fwd_kernel<KK>), dim3((unsigned)blocks), dim3(256), 0, stream, is, os, N, \
-                               H, W, C, OH, OW, stride, pad, include_pad);                                        \
+                               H, W, C, OH, OW, stride, pad, include_pad, ld);                                    \
     } while (0)
     if (k == 3) AVG(3);
     else if (k == 2) AVG(2);

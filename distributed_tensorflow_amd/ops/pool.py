@@ -27,7 +27,7 @@ def _lib():
         P, I = ctypes.c_void_p, ctypes.c_int
         hip.declare("dtf_maxpool_fwd", [P, P, P, I, I, I, I, I, I, I, I, I, P])
         hip.declare("dtf_maxpool_bwd", [P, P, P, I, I, I, I, I, I, I, I, I, P])
-        hip.declare("dtf_avgpool", [P, P, I, I, I, I, I, I, I, I, I, I, I, P])
+        hip.declare("dtf_avgpool", [P, P, I, I, I, I, I, I, I, I, I, I, I, ctypes.c_int64, P])
         hip.declare("dtf_maxpool_fwd_affine", [P, P, P, P, P, I, I, I, I, I, I, I, I, I, P])
         _declared = True
     return lib
@@ -164,15 +164,21 @@ def bn_relu_max_pool2d(x, bn, kernel_size, stride=None, padding=0):
 
 
 class _AvgPoolNHWC(torch.autograd.Function):
+    """``x`` may be a channel slice of a wider NHWC tensor (read in place through its pixel stride); a slice that
+    carries a ``_dtf_gradslot`` (ops/batchnorm.py GradSlices) gets its gradient written into the shared buffer."""
+
     @staticmethod
     def forward(ctx, x, k, stride, pad, include_pad):
+        from . import batchnorm as bnmod
+
         N, C, H, W = x.shape
         OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         y = torch.empty((N, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         rc = _lib().dtf_avgpool(hip.ptr(x), hip.ptr(y), 0, N, H, W, C, OH, OW, k, stride, pad, int(include_pad),
-                                hip.stream())
+                                bnmod._row_stride(x), hip.stream())
         hip.check(rc, "dtf_avgpool fwd")
         ctx.geom = (N, C, H, W, OH, OW, k, stride, pad, int(include_pad))
+        ctx.gradslot = getattr(x, "_dtf_gradslot", None)
         return y
 
     @staticmethod
@@ -180,10 +186,22 @@ class _AvgPoolNHWC(torch.autograd.Function):
         N, C, H, W, OH, OW, k, stride, pad, inc = ctx.geom
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
-        dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
-        rc = _lib().dtf_avgpool(hip.ptr(dy), hip.ptr(dx), 1, N, H, W, C, OH, OW, k, stride, pad, inc, hip.stream())
+        dx, ld = None, C
+        if ctx.gradslot is not None:
+            prov, off, c = ctx.gradslot
+            if prov.shape[1] % 8 == 0 and off % 8 == 0 and c == C and prov.dtype == dy.dtype:
+                dx, ld = prov.slice(off, c), prov.shape[1]
+        if dx is None:
+            dx = torch.empty((N, C, H, W), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        rc = _lib().dtf_avgpool(hip.ptr(dy), hip.ptr(dx), 1, N, H, W, C, OH, OW, k, stride, pad, inc, ld, hip.stream())
         hip.check(rc, "dtf_avgpool bwd")
         return dx, None, None, None, None
+
+
+def _pixel_stride_ok(x):
+    from . import batchnorm as bnmod
+
+    return bnmod._row_stride(x) is not None
 
 
 def avg_pool2d(x, kernel_size, stride=None, padding=0, count_include_pad=True):
@@ -192,7 +210,7 @@ def avg_pool2d(x, kernel_size, stride=None, padding=0, count_include_pad=True):
     Inception-v3 step); these run at the HBM rate (~35 us each)."""
     stride = kernel_size if stride is None else stride
     if (_ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and kernel_size in (2, 3, 5)
-            and x.shape[1] % 8 == 0 and x.is_contiguous(memory_format=torch.channels_last)
+            and x.shape[1] % 8 == 0 and _pixel_stride_ok(x)
             and 0 <= padding < kernel_size and x.shape[2] + 2 * padding >= kernel_size
             and x.shape[3] + 2 * padding >= kernel_size):
         return _AvgPoolNHWC.apply(x, int(kernel_size), int(stride), int(padding), bool(count_include_pad))

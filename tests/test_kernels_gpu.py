@@ -1155,3 +1155,22 @@ def test_resnet_strided_block_subsample_matches_strided_conv(dev, monkeypatch):
     assert float((g1 - g2).norm() / g2.norm()) < 0.03
     for n in p1:
         assert float((p1[n] - p2[n]).norm() / (p2[n].norm() + 1e-6)) < 0.08, n
+
+
+def test_avgpool_reads_a_channel_slice_in_place(dev):
+    from distributed_tensorflow_amd.ops import pool
+
+    torch.manual_seed(0)
+    parent = torch.randn(3, 96, 9, 11, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(3, 32, 9, 11, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for dense in (False, True):
+        p = parent.clone().requires_grad_()
+        x = p[:, 64:96]
+        if dense:
+            x = x.contiguous(memory_format=torch.channels_last)
+        y = pool.avg_pool2d(x, 3, 1, 1, count_include_pad=False)
+        assert "AvgPoolNHWC" in type(y.grad_fn).__name__
+        y.backward(dy)
+        outs.append((y.detach().clone(), p.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
