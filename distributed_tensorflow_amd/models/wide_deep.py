@@ -27,31 +27,38 @@ WIDE_PAD = 8
 
 
 class _SplitDeepWide(torch.autograd.Function):
-    """``e [B, F, D + pad]`` -> ``(deep [B, F*D], wide [B, 1] fp32)``: the deep-tower input and the summed wide
-    weights.  Autograd's version of the two slices materialises two zero-filled ``e``-sized gradients and adds
-    them (three extra passes over the largest activation of the model); here the gradient of ``e`` is written
-    once by a single concatenation."""
+    """``e [B, F, D + pad]`` (+ the dense features) -> ``(h [B, F*D + n_dense + kpad], wide [B, 1] fp32)``: the deep
+    tower's input row -- embeddings, dense features, zero columns up to a whole number of K tiles -- written once, and
+    the summed wide weights.  Autograd's version of the two slices + reshape + concat copies the largest activation of
+    the model three times forward and materialises two zero-filled ``e``-sized gradients backward; here the forward is
+    one strided copy into the final buffer and the gradient of ``e`` one concatenation."""
 
     @staticmethod
-    def forward(ctx, e, D):
-        ctx.shape, ctx.D = e.shape, D
-        deep = e[:, :, :D].reshape(e.shape[0], -1)
+    def forward(ctx, e, dense, D, kpad):
+        B, F_, W = e.shape
+        nd = dense.shape[1]
+        ctx.shape, ctx.D, ctx.nd = e.shape, D, nd
+        h = torch.empty(B, F_ * D + nd + kpad, dtype=e.dtype, device=e.device)
+        h[:, :F_ * D].view(B, F_, D).copy_(e[:, :, :D])
+        h[:, F_ * D:F_ * D + nd].copy_(dense)
+        if kpad:
+            h[:, F_ * D + nd:].zero_()
         wide = e[:, :, D].float().sum(1, keepdim=True)
-        return deep, wide
+        return h, wide
 
     @staticmethod
-    def backward(ctx, d_deep, d_wide):
+    def backward(ctx, d_h, d_wide):
         B, F_, W = ctx.shape
         D = ctx.D
-        dt = d_deep.dtype if d_deep is not None else d_wide.dtype
-        dev = d_deep.device if d_deep is not None else d_wide.device
-        gd = d_deep.reshape(B, F_, D) if d_deep is not None else torch.zeros(B, F_, D, dtype=dt, device=dev)
+        dt = d_h.dtype if d_h is not None else d_wide.dtype
+        dev = d_h.device if d_h is not None else d_wide.device
+        gd = d_h[:, :F_ * D].view(B, F_, D) if d_h is not None else torch.zeros(B, F_, D, dtype=dt, device=dev)
         gw = (d_wide.to(dt).unsqueeze(1).expand(B, F_, 1) if d_wide is not None
               else torch.zeros(B, F_, 1, dtype=dt, device=dev))
         parts = [gd, gw]
         if W - D - 1 > 0:
             parts.append(torch.zeros(B, F_, W - D - 1, dtype=dt, device=dev))
-        return torch.cat(parts, 2), None
+        return torch.cat(parts, 2), None, None, None
 
 
 class WideDeep(nn.Module):
@@ -76,24 +83,20 @@ class WideDeep(nn.Module):
 
     def forward(self, ids, dense):
         e = self.embeddings(ids)                                   # [B, F, D + 8]
-        deep, wide = _SplitDeepWide.apply(e, self.embedding_dim)
-        if deep.is_cuda and deep.dtype == torch.bfloat16:
-            # K6 / K6T path: bias + ReLU in the GEMM epilogue, dZ and the bias gradient in one pass.  The first
-            # layer's 26*64 + 13 = 1677 inputs are padded with zero columns to a whole number of 32-wide K
-            # tiles (the parameter keeps its TF shape; the pad of the 3 MB weight is a few microseconds).
+        if e.is_cuda and e.dtype == torch.bfloat16:
+            # K6 / K6T path: bias + ReLU in the GEMM epilogue, dZ and the bias gradient in one pass.  The first layer's
+            # 26*64 + 13 = 1677 inputs are padded with zero columns to a whole number of 32-wide K tiles (the parameter
+            # keeps its TF shape; the pad of the 3 MB weight is a few microseconds).
             pad = (-self.hidden[0].in_features) % 32
-            parts = [deep, dense.to(deep.dtype)]
-            if pad:
-                parts.append(deep.new_zeros(deep.shape[0], pad))
-            h = torch.cat(parts, 1)
+            h, wide = _SplitDeepWide.apply(e, dense.to(e.dtype), self.embedding_dim, pad)
             for i, lin in enumerate(self.hidden):
                 w = F.pad(lin.weight, (0, pad)) if (i == 0 and pad) else lin.weight
                 h = fused_linear(h, w, lin.bias, act="relu")
-            return self.logits(h).float() + wide + self.wide_dense(dense.to(deep.dtype)).float()
-        h = torch.cat([deep, dense.to(deep.dtype)], 1)
+            return self.logits(h).float() + wide + self.wide_dense(dense.to(e.dtype)).float()
+        h, wide = _SplitDeepWide.apply(e, dense.to(e.dtype), self.embedding_dim, 0)
         for lin in self.hidden:
             h = F.relu(lin(h))
-        return self.logits(h).float() + wide + self.wide_dense(dense.to(deep.dtype)).float()
+        return self.logits(h).float() + wide + self.wide_dense(dense.to(e.dtype)).float()
 
 
 def build(comm=None, device=None, **kw):

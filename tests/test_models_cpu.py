@@ -35,22 +35,24 @@ def test_wide_deep_split_gradient_matches_autograd_slices():
     from distributed_tensorflow_amd.models.wide_deep import _SplitDeepWide
 
     torch.manual_seed(0)
-    B, F_, D, W = 5, 4, 6, 9
+    B, F_, D, W, nd, kpad = 5, 4, 6, 9, 3, 5
+    dense = torch.randn(B, nd)
     e1 = torch.randn(B, F_, W, requires_grad=True)
     e2 = e1.detach().clone().requires_grad_()
-    deep1, wide1 = _SplitDeepWide.apply(e1, D)
-    deep2 = e2[:, :, :D].reshape(B, -1)
+    h1, wide1 = _SplitDeepWide.apply(e1, dense, D, kpad)
+    h2 = torch.cat([e2[:, :, :D].reshape(B, -1), dense, torch.zeros(B, kpad)], 1)
     wide2 = e2[:, :, D].float().sum(1, keepdim=True)
-    assert torch.equal(deep1, deep2) and torch.equal(wide1, wide2)
-    gd, gw = torch.randn_like(deep2), torch.randn_like(wide2)
-    torch.autograd.backward([deep1, wide1], [gd, gw])
-    torch.autograd.backward([deep2, wide2], [gd, gw])
+    assert torch.equal(h1, h2) and torch.equal(wide1, wide2)
+    gh, gw = torch.randn_like(h2), torch.randn_like(wide2)
+    torch.autograd.backward([h1, wide1], [gh, gw])
+    torch.autograd.backward([h2, wide2], [gh, gw])
     assert torch.equal(e1.grad, e2.grad)
     # one output unused
     e3 = e1.detach().clone().requires_grad_()
-    d3, _ = _SplitDeepWide.apply(e3, D)
-    d3.backward(gd)
-    assert torch.equal(e3.grad[:, :, :D].reshape(B, -1), gd) and float(e3.grad[:, :, D:].abs().max()) == 0.0
+    h3, _ = _SplitDeepWide.apply(e3, dense, D, 0)
+    g3 = torch.randn_like(h3)
+    h3.backward(g3)
+    assert torch.equal(e3.grad[:, :, :D].reshape(B, -1), g3[:, :F_ * D]) and float(e3.grad[:, :, D:].abs().max()) == 0.0
 
 
 def test_inception_pool_branch_commutes():
