@@ -52,13 +52,19 @@ class _SplitDeepWide(torch.autograd.Function):
         D = ctx.D
         dt = d_h.dtype if d_h is not None else d_wide.dtype
         dev = d_h.device if d_h is not None else d_wide.device
-        gd = d_h[:, :F_ * D].view(B, F_, D) if d_h is not None else torch.zeros(B, F_, D, dtype=dt, device=dev)
-        gw = (d_wide.to(dt).unsqueeze(1).expand(B, F_, 1) if d_wide is not None
-              else torch.zeros(B, F_, 1, dtype=dt, device=dev))
-        parts = [gd, gw]
+        # three slice writes into one buffer (a concatenation along the 72-wide last axis runs at a third of the rate)
+        de = torch.empty(B, F_, W, dtype=dt, device=dev)
+        if d_h is not None:
+            de[:, :, :D].copy_(d_h[:, :F_ * D].view(B, F_, D))
+        else:
+            de[:, :, :D].zero_()
+        if d_wide is not None:
+            de[:, :, D:D + 1].copy_(d_wide.to(dt).unsqueeze(1).expand(B, F_, 1))
+        else:
+            de[:, :, D:D + 1].zero_()
         if W - D - 1 > 0:
-            parts.append(torch.zeros(B, F_, W - D - 1, dtype=dt, device=dev))
-        return torch.cat(parts, 2), None, None, None
+            de[:, :, D + 1:].zero_()
+        return de, None, None, None
 
 
 class WideDeep(nn.Module):
