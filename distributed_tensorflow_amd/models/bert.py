@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from ..ops import attention
 from ..ops.layernorm import FusedLayerNorm
 from ..ops.cross_entropy import cross_entropy
+from ..ops.embedding import dense_embedding
 from ..ops.linear import FusedLinear
 
 
@@ -99,8 +100,8 @@ class Bert(nn.Module):
     def forward(self, input_ids, token_type_ids, attention_mask, masked_positions):
         B, S = input_ids.shape
         pos = torch.arange(S, device=input_ids.device)
-        x = self.word_embeddings(input_ids) + self.position_embeddings(pos).unsqueeze(0) \
-            + self.token_type_embeddings(token_type_ids)
+        x = dense_embedding(input_ids, self.word_embeddings.weight) + self.position_embeddings(pos).unsqueeze(0) \
+            + dense_embedding(token_type_ids, self.token_type_embeddings.weight)
         x = self.emb_ln(x)
         mask = kv_len = None
         if attention_mask is not None:

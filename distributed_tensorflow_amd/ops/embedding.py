@@ -179,3 +179,45 @@ def embedding_sparse_apply(table, acc, idx, grad, opt="sgd", lr=0.01, eps=1e-10,
     if rc == -31:
         raise ValueError("rowwise_adagrad needs D/8 to divide 64 (D in 8,16,32,...,512)")
     hip.check(rc, "dtf_embedding_sparse_apply")
+
+
+# ---------------------------------------------------------------------------
+# dense-gradient embedding (an ordinary trainable nn.Embedding weight, e.g. BERT's tied word embeddings)
+# ---------------------------------------------------------------------------
+_DENSE_GRAD = os.environ.get("DTF_EMB_DENSE_GRAD", "1") != "0"      # A/B switch
+
+
+class _DenseEmbedding(torch.autograd.Function):
+    """``F.embedding`` whose weight gradient -- a dense ``[V, H]`` tensor -- is built by the K4 sort/segment kernels
+    (``table += grad`` on a zero table: SGD with lr = -1; every row summed in fp32 in a fixed order and rounded once)
+    or, for a handful of rows (token types), by a one-hot GEMM.  The framework's own backward
+    (sort + ``sum_and_scatter`` + segment kernels) took 0.8 ms of a BERT-base step."""
+
+    @staticmethod
+    def forward(ctx, weight, ids):
+        ctx.save_for_backward(ids)
+        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        return torch.nn.functional.embedding(ids, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        V, H = ctx.wshape
+        g2 = dy.reshape(-1, H)
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        idx = ids.reshape(-1)
+        if V <= 64:
+            onehot = (idx.unsqueeze(1) == torch.arange(V, device=idx.device)).to(g2.dtype)
+            return (onehot.t() @ g2).to(ctx.wdtype), None
+        dw = torch.zeros(V, H, dtype=ctx.wdtype, device=dy.device)
+        embedding_sparse_apply(dw, None, idx, g2, opt="sgd", lr=-1.0)
+        return dw, None
+
+
+def dense_embedding(ids, weight):
+    """``F.embedding(ids, weight)``; see :class:`_DenseEmbedding` for the backward."""
+    if (_DENSE_GRAD and weight.is_cuda and weight.dtype in (torch.bfloat16, torch.float32) and ids.dtype == torch.int64
+            and weight.requires_grad and torch.is_grad_enabled() and weight.shape[1] % 8 == 0):
+        return _DenseEmbedding.apply(weight, ids)
+    return torch.nn.functional.embedding(ids, weight)

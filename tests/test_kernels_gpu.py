@@ -1174,3 +1174,32 @@ def test_avgpool_reads_a_channel_slice_in_place(dev):
         y.backward(dy)
         outs.append((y.detach().clone(), p.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("V,H,n,dtype", [(30522, 768, 4096, torch.bfloat16), (2, 768, 4096, torch.bfloat16), (1000, 64, 5000, torch.float32),
+                                         (50, 128, 3000, torch.bfloat16)])
+def test_dense_embedding_gradient(dev, V, H, n, dtype):
+    """Embedding weight gradient through the K4 sort/segment kernels (or the one-hot GEMM for tiny tables) against
+    the framework's fp32 result; repeated ids (hot rows) included."""
+    from distributed_tensorflow_amd.ops import embedding as emb
+
+    torch.manual_seed(0)
+    w = torch.randn(V, H, device=dev).to(dtype)
+    ids = torch.randint(0, V, (8, n // 8), device=dev)
+    ids[0, :200] = 1 % V                       # a hot row
+    dy = torch.randn(8, n // 8, H, device=dev).to(dtype)
+    w1 = w.clone().requires_grad_()
+    y1 = emb.dense_embedding(ids, w1)
+    assert "DenseEmbedding" in type(y1.grad_fn).__name__
+    y1.backward(dy)
+    w2 = w.float().clone().requires_grad_()
+    y2 = torch.nn.functional.embedding(ids, w2)
+    y2.backward(dy.float())
+    assert torch.equal(y1.float(), y2)
+    assert w1.grad.dtype == dtype
+    tol = dict(rtol=1e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(w1.grad.float(), w2.grad, **tol)
+    # deterministic
+    w3 = w.clone().requires_grad_()
+    emb.dense_embedding(ids, w3).backward(dy)
+    assert torch.equal(w3.grad, w1.grad)
