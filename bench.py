@@ -57,6 +57,10 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if os.environ.get("DTF_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["DTF_BENCH_WATCHDOG"]), exit=True)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from distributed_tensorflow_amd.utils import miopen as miopen_cache
 
@@ -77,7 +81,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     hip.lib()
     # DTF_FORCE_COMM=1: keep a live 1-rank RCCL group so the collectives really run on one GPU
-    comm = Comm.from_env(force=bool(int(os.environ.get("DTF_FORCE_COMM", "0"))))
+    comm = Comm.from_env(force=bool(int(os.environ.get("DTF_FORCE_COMM", "0"))), backend=os.environ.get("DTF_COMM_BACKEND"))
     dev = comm.device
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     torch.manual_seed(1234)

@@ -137,7 +137,9 @@ class ShardedPS:
         # -- bind model parameters to the flat pull buffer (zero-copy pull) ---
         if broadcast_init and self._dist:
             for p in self.params:
-                self.comm.broadcast(p.data, 0)
+                # the dense 1-D view of the storage: NHWC (channels_last) conv filters are not "contiguous" in the
+                # default sense, and not every backend accepts that
+                self.comm.broadcast(bucket_ops.dense_storage_view(p.data), 0)
         self.zero_copy = []
         for slot, p in zip(L.slots, self.params):
             assert bucket_ops.is_dense(p.data), "parameter %s is not dense" % slot.name
