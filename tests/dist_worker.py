@@ -67,8 +67,9 @@ def main():
                         max_grad_norm=1.0 if "clip" in case else 0.0)
     push = "all_to_all" if "a2a" in case else "reduce_scatter"
     mode = "stale" if "stale" in case else "sync"
-    ps = ShardedPS(list(model.named_parameters()), comm, opt, bucket_mb=0.02, wire_dtype=torch.float32,
-                   update_mode=mode, push=push)
+    # "tail": one big bucket + the small tail bucket of the first layer (hid_w + hid_b = 78 500 elements)
+    sizes = dict(bucket_mb=1.0, tail_mb=0.3) if "tail" in case else dict(bucket_mb=0.02)
+    ps = ShardedPS(list(model.named_parameters()), comm, opt, wire_dtype=torch.float32, update_mode=mode, push=push, **sizes)
     # the global batch is fixed (64); rank r trains on its 64/W slice
     x, y = mnist_mlp.synthetic_batch(64, seed=11)
     per = 64 // W

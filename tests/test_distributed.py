@@ -62,7 +62,7 @@ def single_process_reference(kind, clip):
 
 
 @pytest.mark.parametrize("case,world", [("sync_momentum", 2), ("sync_momentum_a2a", 2), ("sync_adam", 2),
-                                        ("sync_momentum_clip", 2), ("sync_momentum", 4)])
+                                        ("sync_momentum_clip", 2), ("sync_momentum", 4), ("sync_momentum_tail", 2)])
 def test_sharded_ps_equals_single_process(tmp_path, case, world):
     res = run_ranks(world, case, tmp_path)
     assert res["buckets"] >= 2, "test must exercise several buckets"
