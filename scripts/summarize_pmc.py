@@ -19,7 +19,8 @@ def short(n):
 
 
 ours = ("gemm_bias_act", "act_bwd_bias", "bn_", "sgd_momentum", "adam_apply", "embedding_", "emb_", "bucket_pack",
-        "sumsq", "cast_scale", "colsum")
+        "sumsq", "cast_scale", "colsum", "gemm256p", "gemm_tn", "tn_reduce", "bn2_", "ce_", "plan_", "maxpool", "avgpool",
+        "attn_", "ln_", "filter_flip", "conv_tab")
 vals = collections.defaultdict(lambda: collections.defaultdict(list))   # kernel -> counter -> [values]
 dur = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(d, "*_counter_collection.csv"))):
