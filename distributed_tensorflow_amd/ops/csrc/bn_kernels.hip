@@ -614,8 +614,11 @@ static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, i
     static int target = 0;
     if (target == 0) {
         const char* e = getenv("DTF_BN_BLOCKS");
-        target = e ? atoi(e) : 1024;          // ~4 blocks per CU in total
-        if (target < 64) target = 1024;
+        // 3 blocks per CU in total.  Measured through the whole ResNet-50 / Inception-v3 step (DTF_BN_BLOCKS A/B):
+        // 512: 10 135 / 8 102 images/s, 640: 10 209, 768: 10 391 / 8 228, 896: 10 178, 1024: 10 258 / 8 159,
+        // 1536: 10 221, 2048: 10 271 -- whole multiples of the 256 CUs, and few enough partial rows for the finalize
+        target = e ? atoi(e) : 768;
+        if (target < 64) target = 768;
     }
     int64_t want = target / ct;
     if (want < 1) want = 1;
