@@ -41,6 +41,12 @@ def main():
     ap.add_argument("--model-arg", action="append", default=[], help="key=value forwarded to the model's build()")
     ap.add_argument("--image-size", type=int, default=0, help="0: model default (224 / 299)")
     ap.add_argument("--update-mode", default="sync", choices=["sync", "stale"])
+    ap.add_argument("--staleness", type=int, default=1, help="stale mode: updates become visible this many steps late")
+    ap.add_argument("--wire-dtype", default="auto", choices=["auto", "bf16", "fp32"],
+                    help="dtype of the gradient / parameter traffic (auto: bf16 on GPU, fp32 on CPU)")
+    ap.add_argument("--num-ps", type=int, default=0, help="shard groups (detail.ps); 0 or >= N: one per GPU")
+    ap.add_argument("--device", default=os.environ.get("DTF_BENCH_DEVICE", "cuda"), choices=["cuda", "cpu"],
+                    help="cpu: gloo rehearsal of the multi-rank code path (fp32, use a small --batch/--image-size)")
     ap.add_argument("--push", default="reduce_scatter", choices=["reduce_scatter", "all_to_all"])
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("DTF_MIOPEN_FIND", "0")),
@@ -78,11 +84,19 @@ def main():
         if world == 1 and a.gpus > 1:
             print("bench.py: --gpus %d needs torchrun (WORLD_SIZE=%d)" % (a.gpus, world), file=sys.stderr)
             sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    hip.lib()
+    on_gpu = a.device == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X (or --device cpu for the gloo rehearsal)"
+        hip.lib()
     # DTF_FORCE_COMM=1: keep a live 1-rank RCCL group so the collectives really run on one GPU
-    comm = Comm.from_env(force=bool(int(os.environ.get("DTF_FORCE_COMM", "0"))), backend=os.environ.get("DTF_COMM_BACKEND"))
+    comm = Comm.from_env(device=None if on_gpu else torch.device("cpu"),
+                         force=bool(int(os.environ.get("DTF_FORCE_COMM", "0"))),
+                         backend=os.environ.get("DTF_COMM_BACKEND") or (None if on_gpu else "gloo"))
     dev = comm.device
+
+    def dev_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
     torch.backends.cudnn.benchmark = bool(a.miopen_find)
     torch.manual_seed(1234)
 
@@ -102,7 +116,8 @@ def main():
     model.train()
     opt = mod.default_optimizer()
     ps = ShardedPS(list(model.named_parameters()), comm, opt, bucket_mb=a.bucket_mb,
-                   update_mode=a.update_mode, push=a.push)
+                   update_mode=a.update_mode, push=a.push, num_shards=a.num_ps or None, staleness=a.staleness,
+                   wire_dtype={"bf16": torch.bfloat16, "fp32": torch.float32}.get(a.wire_dtype))
     bkw = {"image_size": a.image_size} if a.image_size else {}
     if getattr(mod, "NEEDS_COMM", False):
         bkw["model"] = model
@@ -117,7 +132,7 @@ def main():
         return loss
 
     graph = None
-    if a.graph and comm.world_size == 1:
+    if a.graph and comm.world_size == 1 and on_gpu:
         # warm up eagerly on a side stream (MIOpen find, allocator), then capture
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -140,18 +155,18 @@ def main():
     for i in range(a.warmup):
         loss = step()
         if comm.rank == 0 and (i < 3 or a.miopen_find):
-            torch.cuda.synchronize()
+            dev_sync()
             print("[bench] warmup step %d done at +%.1f s" % (i + 1, time.perf_counter() - t_w), file=sys.stderr,
                   flush=True)
     comm.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     t_host = time.perf_counter() - t0          # time to ENQUEUE the steps (host-side cost)
-    torch.cuda.synchronize()
+    dev_sync()
     comm.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if comm.world_size > 1:
@@ -167,11 +182,13 @@ def main():
             "metric": "%s (whole node) %s synthetic, PS-sharded variables" % (unit, a.model),
             "value": round(value, 2), "unit": unit, "n_gpus": n, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None if base is None else round(value / base, 3), "dtype": "bf16",
+            "vs_baseline": None if base is None else round(value / base, 3), "dtype": "bf16" if on_gpu else "fp32-cpu-rehearsal",
             "data": "synthetic inputs+labels, random-init weights",
             "config": {"model": a.model + ("_v1.5" if key == "resnet50" else ""), "global_batch": global_batch,
                        "per_gpu_batch": a.batch, "image_size": a.image_size or ("299" if "inception" in key else 224),
-                       "parallelism": "dp%d+ps-shard%d" % (n, n), "push": a.push, "pull": "all_gather",
+                       "parallelism": "dp%d+ps-shard%d" % (n, ps.num_shards), "push": ps.push,
+                       "pull": "all_gather" if ps.family == "scatter" else "broadcast", "staleness": ps.staleness,
+                       "wire_dtype": str(ps.wire_dtype).replace("torch.", ""),
                        "update_mode": a.update_mode, "optimizer": opt.kind, "bucket_mb": a.bucket_mb,
                        "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db),
                        "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),

@@ -192,6 +192,7 @@ def loss_fn(model, batch):
 def default_optimizer():
     from ..parallel.ps_runtime import OptimizerSpec
 
-    # BERT's AdamWeightDecayOptimizer: decoupled decay 0.01, no bias correction
+    # BERT's AdamWeightDecayOptimizer: decoupled decay 0.01, no bias correction, and its exclusion list
+    # ("LayerNorm", "layer_norm", "bias"): those variables form their own bucket group applied with decay 0
     return OptimizerSpec(kind="adam", lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-6, weight_decay=0.01, adamw=True,
-                         bias_correction=False, max_grad_norm=1.0)
+                         bias_correction=False, max_grad_norm=1.0, no_decay=("_ln.", ".bias", "mlm_bias"))

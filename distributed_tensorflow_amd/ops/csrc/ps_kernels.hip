@@ -224,20 +224,31 @@ __global__ __launch_bounds__(256) void bucket_pack_kernel(PackTable t, void* fla
 // ---------------------------------------------------------------------------
 // K8 helpers
 // ---------------------------------------------------------------------------
+// nsrc > 1: x is `nsrc` slabs `src_stride` elements apart (the receive buffer of an all-to-all push);
+// the slabs are summed in fixed order first, so the norm is the norm of the REDUCED gradient and the
+// clipped path needs no separate slab-sum pass.
 template <int DT>
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const void* x, int64_t n, float* partials) {
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const void* x, int64_t n, int nsrc, int64_t src_stride,
+                                                            float* partials) {
     float acc = 0.f;
     const int64_t nvec = n >> 3;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
         float t[8];
         load8<DT>(x, v << 3, t);
+        for (int s = 1; s < nsrc; ++s) {
+            float u[8];
+            load8<DT>(x, (v << 3) + s * src_stride, u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] += u[k];
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc = fmaf(t[k], t[k], acc);
     }
     if (blockIdx.x == 0)
         for (int64_t i = (nvec << 3) + threadIdx.x; i < n; i += blockDim.x) {
-            float t = load1<DT>(x, i);
+            float t = 0.f;
+            for (int s = 0; s < nsrc; ++s) t += load1<DT>(x, i + s * src_stride);
             acc = fmaf(t, t, acc);
         }
     __shared__ float red[4];
@@ -367,14 +378,16 @@ int dtf_bucket_pack(int ntensors, const void* const* ptrs, const int64_t* numel,
     return 0;
 }
 
-// partials: workspace of >= 2048 floats.  out[0] (+)= sum(x^2)
-int dtf_sumsq(const void* x, int dtype, int64_t n, float* partials, float* out, int accumulate,
-              hipStream_t stream) {
+// partials: workspace of >= 2048 floats.  out[0] (+)= sum((sum_s x_s)^2)
+int dtf_sumsq(const void* x, int dtype, int64_t n, int nsrc, int64_t src_stride, float* partials, float* out,
+              int accumulate, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (!aligned16(x)) return -16;
+    if (nsrc < 1) nsrc = 1;
+    if (nsrc > 1 && (src_stride & 7)) return -17;
     const int grid = dtf_stream_grid(n >> 3, 256);
-    if (dtype == DTF_BF16) hipLaunchKernelGGL((sumsq_partial_kernel<DTF_BF16>), dim3(grid), dim3(256), 0, stream, x, n, partials);
-    else hipLaunchKernelGGL((sumsq_partial_kernel<DTF_F32>), dim3(grid), dim3(256), 0, stream, x, n, partials);
+    if (dtype == DTF_BF16) hipLaunchKernelGGL((sumsq_partial_kernel<DTF_BF16>), dim3(grid), dim3(256), 0, stream, x, n, nsrc, src_stride, partials);
+    else hipLaunchKernelGGL((sumsq_partial_kernel<DTF_F32>), dim3(grid), dim3(256), 0, stream, x, n, nsrc, src_stride, partials);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, grid, out, accumulate);
     DTF_CHECK_LAUNCH();
     return 0;
@@ -394,6 +407,6 @@ int dtf_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype, int
 }
 
 int dtf_abi_version() {
-    DTF_CLEAR_ERRORS(); return 1; }
+    DTF_CLEAR_ERRORS(); return 2; }
 
 }  // extern "C"

@@ -35,7 +35,7 @@ def _declare(lib):
         "dtf_sgd_momentum_apply": [P, I, I, L, P, P, P, I, L, P, P, F, F, F, F, F, I, P],
         "dtf_adam_apply": [P, I, I, L, P, P, P, P, I, L, P, P, F, F, F, F, F, F, F, F, I, I, P],
         "dtf_bucket_pack": [I, P, P, P, P, P, I, F, I, P],
-        "dtf_sumsq": [P, I, L, P, P, I, P],
+        "dtf_sumsq": [P, I, L, I, L, P, P, I, P],
         "dtf_cast_scale": [P, I, P, I, L, F, P],
         "dtf_abi_version": [],
     }

@@ -17,19 +17,26 @@ def _workspace(device):
     return w
 
 
-def sumsq(x, out, accumulate=False):
-    """``out[0] (+)= sum(x**2)`` in fp32 with a fixed reduction order."""
+def sumsq(x, out, accumulate=False, n=None, nsrc=1, src_stride=0):
+    """``out[0] (+)= sum(x**2)`` in fp32 with a fixed reduction order.  With ``nsrc > 1`` the operand is
+    ``nsrc`` slabs of ``n`` elements ``src_stride`` apart (an all-to-all receive buffer) that are summed
+    first: the norm of the reduced gradient, without a separate reduction pass."""
     x = x.reshape(-1)
+    n = x.numel() if n is None else int(n)
     if not x.is_cuda:
-        s = (x.float() ** 2).sum()
+        acc = x[:n].float()
+        for s in range(1, nsrc):
+            acc = acc + x[s * src_stride:s * src_stride + n].float()
+        s = (acc ** 2).sum()
         if accumulate:
             out[0] += s
         else:
             out[0] = s
         return out
     assert out.dtype == torch.float32 and x.is_contiguous()
-    rc = hip.lib().dtf_sumsq(hip.ptr(x), hip.dt(x), x.numel(), hip.ptr(_workspace(x.device)), hip.ptr(out),
-                             int(accumulate), hip.stream())
+    assert x.numel() >= (nsrc - 1) * src_stride + n, "sumsq operand too small"
+    rc = hip.lib().dtf_sumsq(hip.ptr(x), hip.dt(x), n, int(nsrc), int(src_stride), hip.ptr(_workspace(x.device)),
+                             hip.ptr(out), int(accumulate), hip.stream())
     hip.check(rc, "dtf_sumsq")
     return out
 

@@ -50,12 +50,20 @@ class Bucket:
     shard: int = 0      # size // world
     shard_off: int = 0  # offset of this bucket's slice inside a rank's shard
     params: list = field(default_factory=list)  # ParamSlot indices, in pack order
+    group: int = 0      # hyper-parameter group (0: decayed, 1: not decayed)
 
 
 class FlatLayout:
     def __init__(self, named_numels, world, bucket_elems, tail_elems=0):
+        """``named_numels``: ``(name, numel)`` or ``(name, numel, group)`` in registration order.  Variables of
+        different ``group`` (e.g. weight-decayed / not decayed) never share a bucket, so one shard-apply launch
+        has one set of hyper-parameters."""
         self.world = int(world)
-        self.slots = [ParamSlot(n, int(k), i) for i, (n, k) in enumerate(named_numels)]
+        self.slots = []
+        groups = []
+        for i, item in enumerate(named_numels):
+            self.slots.append(ParamSlot(item[0], int(item[1]), i))
+            groups.append(int(item[2]) if len(item) > 2 else 0)
         self.buckets = []
         # leading (first-layer) variables that go into the small tail bucket
         n_tail, acc = 0, 0
@@ -67,19 +75,28 @@ class FlatLayout:
                 n_tail += 1
             if n_tail == len(self.slots):
                 n_tail = 0              # the whole model fits: one ordinary bucket
-        cur = Bucket(0)
-        fill = 0
+        open_b = {}                     # group -> [bucket, fill]
         for slot in reversed(self.slots):
             need = _round_up(slot.numel, ALIGN)
-            if fill and (fill + need > bucket_elems or slot.index == n_tail - 1):
-                self._close(cur, fill)
-                cur = Bucket(len(self.buckets))
-                fill = 0
-            slot.bucket = cur.index
-            slot.flat_off = fill          # relative for now
-            cur.params.append(slot.index)
-            fill += need
-        self._close(cur, fill)
+            g = groups[slot.index]
+            if slot.index == n_tail - 1:
+                # tail boundary: everything from here on is the exposed tail
+                for ob in open_b.values():
+                    self._close(*ob)
+                open_b = {}
+            cur = open_b.get(g)
+            if cur is not None and cur[1] and cur[1] + need > bucket_elems:
+                self._close(*cur)
+                cur = None
+            if cur is None:
+                cur = open_b[g] = [Bucket(len(self.buckets), group=g), 0]
+                self.buckets.append(cur[0])
+            slot.bucket = cur[0].index
+            slot.flat_off = cur[1]          # relative for now
+            cur[0].params.append(slot.index)
+            cur[1] += need
+        for ob in open_b.values():
+            self._close(*ob)
         start = shard_off = 0
         for b in self.buckets:
             b.start, b.shard_off = start, shard_off
@@ -93,7 +110,6 @@ class FlatLayout:
     def _close(self, b, fill):
         b.size = _round_up(max(fill, 1), self.world * ALIGN)
         b.shard = b.size // self.world
-        self.buckets.append(b)
 
     # -- address translation ------------------------------------------------
     def shard_range(self, bucket, rank):

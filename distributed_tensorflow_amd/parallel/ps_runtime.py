@@ -19,12 +19,24 @@ backward; ``step()`` joins the streams.  No host synchronisation in the step.
 Update modes:
   ``sync``  -- push/apply/pull every step before the next forward
                (TF ``SyncReplicasOptimizer`` semantics; deterministic).
-  ``stale`` -- bounded staleness 1: step t's push/apply/pull overlaps with the
-               whole forward+backward of step t+1, which still runs on the
-               parameters from before update t (the collective counterpart of
-               TF1's default asynchronous PS update; deterministic).
-True any-order asynchronous updates exist in the dedicated placement
-(``parallel/dedicated_ps.py``), where PS tasks are separate processes.
+  ``stale`` -- bounded staleness ``s`` (default 1): step t's push/apply/pull overlaps
+               with the whole forward+backward of steps t+1 .. t+s, which still run on
+               the parameters from before update t (stale-synchronous-parallel: the
+               collective counterpart of TF1's asynchronous PS update; deterministic).
+True any-order asynchronous updates: ``parallel/async_ps.py`` (colocated GPU ranks,
+one-sided shard apply over xGMI peer mappings, no collectives and no barrier) and
+``parallel/dedicated_ps.py`` (PS tasks as separate processes).
+
+Shard groups: ``num_shards`` is the job's ``detail.ps`` (the reference creates that many
+PS tasks which own the variables, ``handlers/train_handler.py:96-112``).  ``P >= W``
+spreads the state uniformly over all W ranks (push = reduce-scatter, pull = all-gather,
+every xGMI link busy).  ``P < W`` is the classic "few parameter servers" topology: ranks
+0..P-1 host the state, push = ``reduce`` of slice j to rank j, pull = ``broadcast`` of
+slice j from rank j.
+
+Gradient clipping (``max_grad_norm``): packs and pushes still run from the backward
+hooks; only sum-of-squares -> scalar all-reduce -> apply -> pull wait for the end of
+backward.
 """
 from __future__ import annotations
 
@@ -71,6 +83,7 @@ class OptimizerSpec:
     adamw: bool = True
     bias_correction: bool = True
     max_grad_norm: float = 0.0    # 0 = no clipping
+    no_decay: tuple = ()          # name substrings of variables exempt from weight decay (BERT: LayerNorm, bias)
 
     @property
     def slots(self):
@@ -80,6 +93,9 @@ class OptimizerSpec:
         if self.kind == "momentum":
             return ("Momentum",)
         return ()
+
+    def decays(self, name):
+        return not any(pat in name for pat in self.no_decay)
 
 
 def trainable(named_params):
@@ -91,7 +107,7 @@ def trainable(named_params):
 class ShardedPS:
     def __init__(self, named_params, comm: Comm = None, opt: OptimizerSpec = None, bucket_mb=32.0,
                  wire_dtype=None, update_mode="sync", push="reduce_scatter", overlap=True,
-                 broadcast_init=True, tail_mb=4.0):
+                 broadcast_init=True, tail_mb=4.0, num_shards=None, staleness=1):
         self.comm = comm or Comm.single()
         self.opt = opt or OptimizerSpec()
         self.named_params = trainable(named_params)
@@ -102,31 +118,46 @@ class ShardedPS:
         self.wire_dtype = wire_dtype or (torch.bfloat16 if self.is_cuda else torch.float32)
         assert update_mode in ("sync", "stale"), update_mode
         assert push in ("reduce_scatter", "all_to_all"), push
-        self.update_mode, self.push = update_mode, push
+        self.update_mode = update_mode
+        self.staleness = max(1, int(staleness)) if update_mode == "stale" else 0
         W, r = self.comm.world_size, self.comm.rank
+        # shard groups (detail.ps): P >= W -> uniform over the W ranks; P < W -> ranks 0..P-1 host the state
+        P = W if (not num_shards or int(num_shards) >= W) else max(1, int(num_shards))
+        self.num_shards = P
+        self.family = "scatter" if P == W else "reduce"
+        self.hosted = r < P
+        self.push = push if self.family == "scatter" else "reduce"
         self._dist = self.comm.live          # collectives are real (W > 1, or a forced 1-rank group)
         esize = torch.empty((), dtype=self.wire_dtype).element_size()
         # tail_mb: size cap of the bucket holding the FIRST layers -- the only one whose push/apply/pull is
         # exposed after backward (parallel/layout.py)
-        self.layout = FlatLayout([(n, p.numel()) for n, p in self.named_params], W,
+        decays = [self.opt.decays(n) for n, _ in self.named_params]
+        split_groups = self.opt.weight_decay > 0 and not all(decays)
+        self.layout = FlatLayout([(n, p.numel(), 0 if (d or not split_groups) else 1)
+                                  for (n, p), d in zip(self.named_params, decays)], P,
                                  max(1, int(bucket_mb * (1 << 20) / esize)), int(tail_mb * (1 << 20) / esize))
         L = self.layout
         dev = self.device
         self.param_flat = torch.zeros(L.total, dtype=self.wire_dtype, device=dev)
-        self.grad_flat = torch.zeros(L.total, dtype=self.wire_dtype, device=dev)
-        self.master = torch.zeros(L.shard_total, dtype=torch.float32, device=dev)
-        self.slot_m = torch.zeros(L.shard_total, dtype=torch.float32, device=dev) \
+        n_state = L.shard_total if self.hosted else 0
+        self.master = torch.zeros(n_state, dtype=torch.float32, device=dev)
+        self.slot_m = torch.zeros(n_state, dtype=torch.float32, device=dev) \
             if self.opt.kind in ("momentum", "adam") else None
-        self.slot_v = torch.zeros(L.shard_total, dtype=torch.float32, device=dev) \
+        self.slot_v = torch.zeros(n_state, dtype=torch.float32, device=dev) \
             if self.opt.kind == "adam" else None
-        if self._dist:
+        # gradient staging: one flat buffer, or a ring of `staleness` of them (a stale pipeline reads its
+        # gradients while later steps pack theirs)
+        nring = max(1, self.staleness)
+        self._grad_ring = [torch.zeros(L.total, dtype=self.wire_dtype, device=dev) for _ in range(nring)]
+        self.grad_flat = self._grad_ring[0]
+        if self._dist and self.family == "scatter":
             self.grad_shard = torch.zeros(L.total if push == "all_to_all" else L.shard_total,
                                           dtype=self.wire_dtype, device=dev)
             self.shard_out = torch.zeros(L.shard_total, dtype=self.wire_dtype, device=dev)
         else:
             self.grad_shard = self.shard_out = None
-        self.pull_staging = torch.zeros(L.total, dtype=self.wire_dtype, device=dev) \
-            if update_mode == "stale" else None
+        self._staging = [torch.zeros(L.total, dtype=self.wire_dtype, device=dev) for _ in range(self.staleness)]
+        self.pull_staging = self._staging[0] if self._staging else None
         # hyper-parameters live in device memory so a captured hipGraph replays
         # with new values: [lr, extra grad scale, step]
         self.hyper = torch.tensor([self.opt.lr, 1.0, 1.0], dtype=torch.float32, device=dev)
@@ -135,51 +166,59 @@ class ShardedPS:
         self._lr = self.opt.lr
 
         # -- bind model parameters to the flat pull buffer (zero-copy pull) ---
-        if broadcast_init and self._dist:
-            for p in self.params:
-                # the dense 1-D view of the storage: NHWC (channels_last) conv filters are not "contiguous" in the
-                # default sense, and not every backend accepts that
-                self.comm.broadcast(bucket_ops.dense_storage_view(p.data), 0)
         self.zero_copy = []
         for slot, p in zip(L.slots, self.params):
             assert bucket_ops.is_dense(p.data), "parameter %s is not dense" % slot.name
-            region = self.param_flat[slot.flat_off:slot.flat_off + slot.numel]
-            region.copy_(bucket_ops.dense_storage_view(p.data))
+            self.param_flat[slot.flat_off:slot.flat_off + slot.numel].copy_(bucket_ops.dense_storage_view(p.data))
+        if broadcast_init and self._dist:
+            # the chief's initial values, one collective per BUCKET of the flat buffer (not one per variable:
+            # 161 broadcasts for ResNet-50, ~200 for BERT)
+            for bk in L.buckets:
+                self.comm.broadcast(self.param_flat[bk.start:bk.start + bk.size], 0)
+        for slot, p in zip(L.slots, self.params):
             zc = p.dtype == self.wire_dtype
             if zc:
                 p.data = torch.as_strided(self.param_flat, p.shape, p.stride(), slot.flat_off)
             self.zero_copy.append(zc)
+        self._unpack_needed = not all(self.zero_copy)
+        if self._unpack_needed and broadcast_init and self._dist:
+            self._unpack_params()
         # fp32 master copy of the owned slices.  With a bf16 wire the master is
         # seeded from the (rounded) wire values, identical on every rank.
-        for b in L.buckets:
-            lo, hi = L.shard_range(b.index, r)
-            self.master[b.shard_off:b.shard_off + b.shard].copy_(self.param_flat[lo:hi])
+        if self.hosted:
+            for b in L.buckets:
+                lo, hi = L.shard_range(b.index, r)
+                self.master[b.shard_off:b.shard_off + b.shard].copy_(self.param_flat[lo:hi])
         self._plans = []
         for b in L.buckets:
             numels = [L.slots[i].numel for i in b.params]
             offs = [L.slots[i].flat_off for i in b.params]
             self._plans.append(bucket_ops.PackPlan(numels, offs))
-        self._unpack_needed = not all(self.zero_copy)
 
         # -- overlap machinery ------------------------------------------------
         self.overlap = bool(overlap) and update_mode == "sync"
         self.comm_stream = torch.cuda.Stream(device=dev) if self.is_cuda else None
         self._pending = [len(b.params) for b in L.buckets]
         self._launched = [False] * len(L.buckets)
+        self._pushed = [None] * len(L.buckets)
         self._slot_bucket = {}
         self._hooks = []
         for slot, p in zip(L.slots, self.params):
             self._slot_bucket[id(p)] = slot.bucket
             if self.overlap:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-        self._inflight = False
+        self._inflight = [None] * self.staleness      # per ring slot: event of the pipeline in flight (or True)
+        self._last_slot = None
 
     # ------------------------------------------------------------------ hooks
     def _on_grad(self, p):
         b = self._slot_bucket[id(p)]
         self._pending[b] -= 1
-        if self._pending[b] == 0 and not self._launched[b] and self.gnorm_sq is None:
-            self._launch_bucket(b)
+        if self._pending[b] == 0 and not self._launched[b]:
+            if self.gnorm_sq is None:
+                self._launch_bucket(b)
+            else:
+                self._launch_push(b)
 
     @contextlib.contextmanager
     def _on_comm_stream(self):
@@ -205,15 +244,25 @@ class ShardedPS:
         return out
 
     # ------------------------------------------------------------- pipeline
-    def _pack(self, b):
-        self._plans[b].pack(self._grads_of(b), self.grad_flat, 1.0 / self.comm.world_size)
+    def _pack(self, b, grad_flat=None):
+        self._plans[b].pack(self._grads_of(b), self.grad_flat if grad_flat is None else grad_flat,
+                            1.0 / self.comm.world_size)
 
-    def _push(self, b):
+    def _push(self, b, grad_flat=None):
+        """-> (reduced gradient of this rank's slice, nsrc, src_stride), or None when this rank hosts no
+        state of the bucket (``P < W``)."""
         L, W = self.layout, self.comm.world_size
         bk = L.buckets[b]
+        gf = self.grad_flat if grad_flat is None else grad_flat
+        full = gf[bk.start:bk.start + bk.size]
         if not self._dist:
-            return self.grad_flat[bk.start:bk.start + bk.size], 1, 0
-        full = self.grad_flat[bk.start:bk.start + bk.size]
+            return full, 1, 0
+        if self.family == "reduce":
+            # worker -> PS j: one rooted reduce per shard group, in place in the staging bucket
+            for j in range(self.num_shards):
+                self.comm.reduce(full[j * bk.shard:(j + 1) * bk.shard], j)
+            r = self.comm.rank
+            return (full[r * bk.shard:(r + 1) * bk.shard], 1, 0) if self.hosted else None
         if self.push == "all_to_all":
             recv = self.grad_shard[bk.start:bk.start + bk.size]
             self.comm.all_to_all(recv, full)
@@ -222,27 +271,34 @@ class ShardedPS:
         self.comm.reduce_scatter(out, full)
         return out, 1, 0
 
-    def _apply(self, b, g, nsrc, src_stride):
-        L, W, r = self.layout, self.comm.world_size, self.comm.rank
+    def _apply(self, b, pushed, dst=None):
+        if pushed is None:
+            return
+        g, nsrc, src_stride = pushed
+        L, r = self.layout, self.comm.rank
         bk = L.buckets[b]
         sl = slice(bk.shard_off, bk.shard_off + bk.shard)
+        dst = self.param_flat if dst is None else dst
         if not self._dist:
-            dst = self.pull_staging if self.update_mode == "stale" else self.param_flat
             p_out = dst[bk.start:bk.start + bk.size]
+        elif self.family == "reduce":
+            lo, hi = L.shard_range(b, r)
+            p_out = dst[lo:hi]
         else:
             p_out = self.shard_out[sl]
         o = self.opt
+        wd = o.weight_decay if bk.group == 0 else 0.0
         common = dict(grad_scale=1.0, nsrc=nsrc, src_stride=src_stride, hyper=self.hyper,
                       gnorm_sq=self.gnorm_sq, max_norm=o.max_grad_norm)
         if o.kind == "adam":
             optim_ops.adam_apply(g, self.master[sl], self.slot_m[sl], self.slot_v[sl], p_out, lr=self._lr,
-                                 beta1=o.beta1, beta2=o.beta2, eps=o.eps, wd=o.weight_decay, adamw=o.adamw,
+                                 beta1=o.beta1, beta2=o.beta2, eps=o.eps, wd=wd, adamw=o.adamw,
                                  bias_correction=o.bias_correction, step=self.global_step + 1, **common)
         else:
             mom = o.momentum if o.kind == "momentum" else 0.0
             m = self.slot_m[sl] if self.slot_m is not None else self._scratch_m(bk.shard)
             optim_ops.sgd_momentum_apply(g, self.master[sl], m, p_out, lr=self._lr, momentum=mom,
-                                         wd=o.weight_decay, nesterov=o.nesterov, **common)
+                                         wd=wd, nesterov=o.nesterov, **common)
 
     def _scratch_m(self, n):
         # plain SGD: momentum 0 makes m == g; a scratch slot keeps one kernel
@@ -250,12 +306,18 @@ class ShardedPS:
             self._m_scratch = torch.zeros(n, dtype=torch.float32, device=self.device)
         return self._m_scratch[:n]
 
-    def _pull(self, b):
-        L, W = self.layout, self.comm.world_size
+    def _pull(self, b, dst=None):
+        L = self.layout
         if not self._dist:
             return
         bk = L.buckets[b]
-        dst = self.pull_staging if self.update_mode == "stale" else self.param_flat
+        dst = self.param_flat if dst is None else dst
+        if self.family == "reduce":
+            # PS j -> every worker: one broadcast per shard group, in place
+            for j in range(self.num_shards):
+                lo, hi = L.shard_range(b, j)
+                self.comm.broadcast(dst[lo:hi], j)
+            return
         self.comm.all_gather(dst[bk.start:bk.start + bk.size],
                              self.shard_out[bk.shard_off:bk.shard_off + bk.shard])
 
@@ -266,11 +328,20 @@ class ShardedPS:
             with trace_range("ps/pack/b%d" % b):
                 self._pack(b)
             with trace_range("ps/push/b%d" % b):
-                g, nsrc, stride = self._push(b)
+                pushed = self._push(b)
             with trace_range("ps/apply/b%d" % b):
-                self._apply(b, g, nsrc, stride)
+                self._apply(b, pushed)
             with trace_range("ps/pull/b%d" % b):
                 self._pull(b)
+
+    def _launch_push(self, b):
+        """Clipped path, from the hooks: pack -> push only; apply waits for the global norm."""
+        self._launched[b] = True
+        with self._on_comm_stream():
+            with trace_range("ps/pack/b%d" % b):
+                self._pack(b)
+            with trace_range("ps/push/b%d" % b):
+                self._pushed[b] = self._push(b)
 
     # ------------------------------------------------------------------ step
     def step(self):
@@ -294,49 +365,82 @@ class ShardedPS:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
 
     def _step_clipped(self):
-        """Global-norm clipping needs every reduced shard before any apply."""
+        """Global-norm clipping needs every reduced shard before any apply: the packs and pushes already ran
+        from the hooks (behind backward); what is left is sum-of-squares of the reduced slices (the W-way slab
+        sum of an all-to-all push fused in), one scalar all-reduce, then apply + pull per bucket."""
         nb = len(self.layout.buckets)
+        for b in range(nb):
+            if not self._launched[b]:
+                self._launch_push(b)
         with self._on_comm_stream():
-            pushed = []
-            for b in range(nb):
-                self._pack(b)
-                pushed.append(self._push(b))
             first = True
-            for b, (g, nsrc, stride) in enumerate(pushed):
+            for b in range(nb):
+                pushed = self._pushed[b]
+                if pushed is None:
+                    continue
+                g, nsrc, stride = pushed
                 bk = self.layout.buckets[b]
-                if nsrc > 1:   # all_to_all slabs: reduce first so the norm sees the sum
-                    acc = g[:bk.shard].float()
-                    for s in range(1, nsrc):
-                        acc += g[s * stride:s * stride + bk.shard].float()
-                    g = acc.to(self.wire_dtype)
-                    pushed[b] = (g, 1, 0)
                 n = bk.shard if self._dist else bk.size
-                reduce_ops.sumsq(g[:n], self.gnorm_sq, accumulate=not first)
+                reduce_ops.sumsq(g, self.gnorm_sq, accumulate=not first, n=n, nsrc=nsrc, src_stride=stride)
                 first = False
+            if first:
+                self.gnorm_sq.zero_()       # this rank hosts nothing (P < W): contributes 0 to the norm
             self.comm.all_reduce(self.gnorm_sq)
-            for b, (g, nsrc, stride) in enumerate(pushed):
-                self._apply(b, g, nsrc, stride)
+            for b in range(nb):
+                self._apply(b, self._pushed[b])
                 self._pull(b)
             self.hyper[2:3].add_(1.0)
+        self._pushed = [None] * nb
         self._join()
+
+    def _wait_slot(self, slot):
+        ev = self._inflight[slot]
+        if ev is None:
+            return False
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return True
 
     def _step_stale(self):
         nb = len(self.layout.buckets)
-        # 1. the previous step's pipeline must be done; adopt its parameters
-        self._join()
-        if self._inflight:
-            self.param_flat.copy_(self.pull_staging)
+        slot = self.global_step % self.staleness
+        staging, ring = self._staging[slot], self._grad_ring[slot]
+        # 1. the pipeline launched `staleness` steps ago must be done; adopt its parameters
+        if self._wait_slot(slot):
+            self.param_flat.copy_(staging)
         # 2. stage this step's gradients, then run the pipeline behind the
-        #    next forward/backward
+        #    next `staleness` forward/backward passes
         for b in range(nb):
-            self._pack(b)
+            self._pack(b, ring)
         with self._on_comm_stream():
+            first = True
+            pushed = []
             for b in range(nb):
-                g, nsrc, stride = self._push(b)
-                self._apply(b, g, nsrc, stride)
-                self._pull(b)
+                pb = self._push(b, ring)
+                pushed.append(pb)
+                if self.gnorm_sq is None:
+                    self._apply(b, pb, staging)
+                    self._pull(b, staging)
+                elif pb is not None:
+                    bk = self.layout.buckets[b]
+                    reduce_ops.sumsq(pb[0], self.gnorm_sq, accumulate=not first,
+                                     n=bk.shard if self._dist else bk.size, nsrc=pb[1], src_stride=pb[2])
+                    first = False
+            if self.gnorm_sq is not None:
+                if first:
+                    self.gnorm_sq.zero_()
+                self.comm.all_reduce(self.gnorm_sq)
+                for b in range(nb):
+                    self._apply(b, pushed[b], staging)
+                    self._pull(b, staging)
             self.hyper[2:3].add_(1.0)
-        self._inflight = True
+            if self.comm_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(self.comm_stream)
+                self._inflight[slot] = ev
+            else:
+                self._inflight[slot] = True
+        self._last_slot = slot
 
     def _finish_step(self):
         if self._unpack_needed:
@@ -348,11 +452,13 @@ class ShardedPS:
         self.global_step += 1
 
     def flush(self):
-        """Drain a stale-mode pipeline (end of training / before checkpoint)."""
+        """Drain a stale-mode pipeline (end of training / before checkpoint): the newest pipeline's output
+        holds every update."""
         self._join()
-        if self.update_mode == "stale" and self._inflight:
-            self.param_flat.copy_(self.pull_staging)
-            self._inflight = False
+        if self.update_mode == "stale" and self._last_slot is not None:
+            self.param_flat.copy_(self._staging[self._last_slot])
+            self._inflight = [None] * self.staleness
+            self._last_slot = None
             if self._unpack_needed:
                 self._unpack_params()
 
@@ -383,12 +489,19 @@ class ShardedPS:
 
     def full_master(self):
         """All-gather the fp32 master weights (tests / export): flat [total]."""
-        L, W = self.layout, self.comm.world_size
+        L = self.layout
         self.flush()
         out = torch.zeros(L.total, dtype=torch.float32, device=self.device)
         for bk in L.buckets:
-            sl = self.master[bk.shard_off:bk.shard_off + bk.shard].contiguous()
-            self.comm.all_gather(out[bk.start:bk.start + bk.size], sl)
+            if self.family == "reduce" and self._dist:
+                for j in range(self.num_shards):
+                    lo, hi = L.shard_range(bk.index, j)
+                    if j == self.comm.rank:
+                        out[lo:hi].copy_(self.master[bk.shard_off:bk.shard_off + bk.shard])
+                    self.comm.broadcast(out[lo:hi], j)
+            else:
+                sl = self.master[bk.shard_off:bk.shard_off + bk.shard].contiguous()
+                self.comm.all_gather(out[bk.start:bk.start + bk.size], sl)
         return out
 
     def param_from_flat(self, flat, index):

@@ -54,22 +54,75 @@ def widedeep_case(comm, out_dir):
     comm.close()
 
 
+def real_layout_case(comm, out_dir, case):
+    """The shipped ResNet-50 / BERT-base variable layouts (tail bucket, several 32 MB buckets, decay groups)
+    with the bf16 wire, hooks launching the pipeline during backward, over W gloo ranks: every replica must hold
+    bitwise the same parameters after each step, and the owned master shards must reassemble to them."""
+    import torch.distributed as dist
+
+    from distributed_tensorflow_amd.models import get_model_module
+
+    r, W = comm.rank, comm.world_size
+    name = "bert" if "bert" in case else "resnet50"
+    mod = get_model_module(name)
+    torch.manual_seed(3 + r)            # DIFFERENT init per rank: broadcast_init must make them equal
+    model = mod.build()
+    opt = mod.default_optimizer()
+    push = "all_to_all" if "a2a" in case else "reduce_scatter"
+    ps = ShardedPS(list(model.named_parameters()), comm, opt, wire_dtype=torch.bfloat16, push=push,
+                   num_shards=1 if "ps1" in case else None)
+    kw = dict(seq_len=16) if name == "bert" else dict(image_size=32)
+    batch = mod.synthetic_batch(2, seed=50 + r, **kw)
+    sums, losses = [], []
+    for _ in range(2):
+        loss = mod.loss_fn(model, batch)
+        loss.backward()
+        ps.step()
+        losses.append(float(loss.detach()))
+        # replicas in sync: compare an exact fingerprint of the pulled parameters across ranks
+        fp = ps.param_flat.view(torch.int16).to(torch.int64)
+        sig = torch.stack([fp.sum(), (fp * torch.arange(1, fp.numel() + 1) % 1000003).sum()])
+        all_sig = [torch.zeros_like(sig) for _ in range(W)]
+        dist.all_gather(all_sig, sig)
+        assert all(torch.equal(all_sig[0], x) for x in all_sig), "replicas diverged: %s" % all_sig
+        sums.append(int(sig[0]))
+    full = ps.full_master()
+    wire = ps.param_flat.float()
+    # what every worker computes with is the bf16 rounding of the fp32 master the PS shards hold
+    torch.testing.assert_close(full.to(torch.bfloat16).float(), wire, rtol=0, atol=0)
+    # the model's own (fp32) tensors were refreshed from the pulled wire values
+    for i, (n, p) in enumerate(ps.named_params):
+        assert torch.equal(p.detach().reshape(-1), ps.param_from_flat(wire, i).reshape(-1).to(p.dtype)), n
+    if r == 0:
+        torch.save({"losses": losses, "buckets": len(ps.layout.buckets), "sums": sums,
+                    "groups": sorted({b.group for b in ps.layout.buckets}),
+                    "bucket_sizes": [b.size for b in ps.layout.buckets]},
+                   os.path.join(out_dir, "result_%s_w%d.pt" % (case, W)))
+    comm.barrier()
+    comm.close()
+
+
 def main():
     case, out_dir = sys.argv[1], sys.argv[2]
     comm = Comm.from_env(torch.device("cpu"), backend="gloo")
     r, W = comm.rank, comm.world_size
     if case == "widedeep":
         return widedeep_case(comm, out_dir)
+    if case.startswith("real_"):
+        return real_layout_case(comm, out_dir, case)
     torch.manual_seed(7)   # same init everywhere; broadcast_init also enforces it
     model = mnist_mlp.build()
     kind = "adam" if "adam" in case else "momentum"
-    opt = OptimizerSpec(kind=kind, lr=0.01 if kind == "adam" else 0.1, momentum=0.9, weight_decay=1e-4,
-                        max_grad_norm=1.0 if "clip" in case else 0.0)
+    opt = OptimizerSpec(kind=kind, lr=0.01 if kind == "adam" else 0.1, momentum=0.9,
+                        weight_decay=0.05 if "nodecay" in case else 1e-4,
+                        max_grad_norm=1.0 if "clip" in case else 0.0,
+                        no_decay=("_b",) if "nodecay" in case else ())
     push = "all_to_all" if "a2a" in case else "reduce_scatter"
     mode = "stale" if "stale" in case else "sync"
     # "tail": one big bucket + the small tail bucket of the first layer (hid_w + hid_b = 78 500 elements)
     sizes = dict(bucket_mb=1.0, tail_mb=0.3) if "tail" in case else dict(bucket_mb=0.02)
-    ps = ShardedPS(list(model.named_parameters()), comm, opt, wire_dtype=torch.float32, update_mode=mode, push=push, **sizes)
+    ps = ShardedPS(list(model.named_parameters()), comm, opt, wire_dtype=torch.float32, update_mode=mode, push=push,
+                   num_shards=1 if "ps1" in case else None, staleness=2 if "stale2" in case else 1, **sizes)
     # the global batch is fixed (64); rank r trains on its 64/W slice
     x, y = mnist_mlp.synthetic_batch(64, seed=11)
     per = 64 // W

@@ -39,12 +39,17 @@ def run_ranks(world, case, out_dir, timeout=180):
     return torch.load(os.path.join(out_dir, "result_%s_w%d.pt" % (case, world)), weights_only=True)
 
 
-def single_process_reference(kind, clip):
+def single_process_reference(kind, clip, nodecay=False):
     from distributed_tensorflow_amd.models import mnist_mlp
 
     torch.manual_seed(7)
     model = mnist_mlp.build()
-    if kind == "adam":
+    if kind == "adam" and nodecay:
+        named = list(model.named_parameters())
+        opt = torch.optim.AdamW([{"params": [p for n, p in named if "_b" not in n], "weight_decay": 0.05},
+                                 {"params": [p for n, p in named if "_b" in n], "weight_decay": 0.0}],
+                                lr=0.01, betas=(0.9, 0.999), eps=1e-8)
+    elif kind == "adam":
         opt = torch.optim.AdamW(model.parameters(), lr=0.01, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4)
     else:
         opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
@@ -62,11 +67,18 @@ def single_process_reference(kind, clip):
 
 
 @pytest.mark.parametrize("case,world", [("sync_momentum", 2), ("sync_momentum_a2a", 2), ("sync_adam", 2),
-                                        ("sync_momentum_clip", 2), ("sync_momentum", 4), ("sync_momentum_tail", 2)])
+                                        ("sync_momentum_clip", 2), ("sync_momentum", 4), ("sync_momentum_tail", 2),
+                                        ("sync_momentum_clip_a2a", 4), ("sync_adam_clip", 8),
+                                        ("sync_momentum_ps1", 2), ("sync_adam_clip_ps1", 4),
+                                        ("sync_adam_nodecay", 2)])
 def test_sharded_ps_equals_single_process(tmp_path, case, world):
+    """ps1: ``detail.ps = 1`` with W workers -- rank 0 hosts every variable, push = rooted reduce,
+    pull = broadcast.  clip: packs and pushes from the backward hooks, norm + apply afterwards.
+    nodecay: bias variables exempt from weight decay live in their own bucket group."""
     res = run_ranks(world, case, tmp_path)
     assert res["buckets"] >= 2, "test must exercise several buckets"
-    ref, ref_losses = single_process_reference("adam" if "adam" in case else "momentum", "clip" in case)
+    ref, ref_losses = single_process_reference("adam" if "adam" in case else "momentum", "clip" in case,
+                                               "nodecay" in case)
     for n, p in ref.items():
         torch.testing.assert_close(res["params"][n], p, rtol=2e-4, atol=2e-5, msg=lambda m: "%s: %s" % (n, m))
     # the mean of the per-rank losses is the global-batch loss only at step 0 for rank 0's slice;
@@ -86,6 +98,31 @@ def test_stale_mode_is_one_step_behind_and_converges(tmp_path):
     assert res["losses"][-1] < res["losses"][0]
     # staleness 1: the first two losses are computed on the same (initial) parameters
     assert abs(res["losses"][0] - res["losses"][1]) < 1e-6
+
+
+def test_stale2_is_two_steps_behind(tmp_path):
+    """Bounded staleness 2: updates become visible two steps late (three losses on the initial parameters), the
+    result is deterministic, and training still converges."""
+    res = run_ranks(2, "stale2_momentum", tmp_path / "a")
+    assert abs(res["losses"][0] - res["losses"][1]) < 1e-6 and abs(res["losses"][0] - res["losses"][2]) < 1e-6
+    assert abs(res["losses"][3] - res["losses"][0]) > 1e-4
+    assert res["losses"][-1] < res["losses"][0]
+    again = run_ranks(2, "stale2_momentum", tmp_path / "b")
+    for n in res["params"]:
+        assert torch.equal(res["params"][n], again["params"][n])
+
+
+@pytest.mark.parametrize("case,world", [("real_resnet50", 2), ("real_resnet50_a2a", 4), ("real_bert", 2),
+                                        ("real_bert_ps1", 2)])
+def test_real_layouts_bf16_wire_replicas_stay_in_sync(tmp_path, case, world):
+    """The shipped ResNet-50 / BERT-base layouts (32 MB buckets + tail bucket, BERT's clipped AdamW with the
+    no-decay group) with the bf16 wire over gloo: asserts inside the worker (replicas bitwise equal, master ==
+    pulled parameters); here only that several buckets / both decay groups were really exercised."""
+    res = run_ranks(world, case, tmp_path, timeout=400)
+    assert res["buckets"] >= 3, res
+    if "bert" in case:
+        assert res["groups"] == [0, 1], res
+    assert all(l == l and l < 1e4 for l in res["losses"])
 
 
 def test_checkpoint_resharding_2_to_4_ranks(tmp_path):
