@@ -131,18 +131,27 @@ def prepare(model, device):
 
 
 def tf_variable_names(model):
+    """torch name -> TF name, or -> ``[(TF name, row0, row1), ...]`` for the packed QKV projection, which the
+    checkpoint index lists as google-research/bert's three variables ``attention/self/{query,key,value}/{kernel,bias}``
+    (row ranges of the same shard bytes: output rows are ordered q, k, v)."""
     out = {}
     ln = {"weight": "gamma", "bias": "beta"}
     kb = {"weight": "kernel", "bias": "bias"}
+    H = model.hidden
     for n, _ in model.named_parameters():
         p = n.split(".")
+        if p[0] == "layers" and p[2] == "qkv":
+            base = "bert/encoder/layer_%s/attention/self/" % p[1]
+            out[n] = [(base + "%s/%s" % (part, kb[p[3]]), i * H, (i + 1) * H)
+                      for i, part in enumerate(("query", "key", "value"))]
+            continue
         if p[0] in ("word_embeddings", "position_embeddings", "token_type_embeddings"):
             tf = "bert/embeddings/" + p[0]
         elif p[0] == "emb_ln":
             tf = "bert/embeddings/LayerNorm/" + ln[p[1]]
         elif p[0] == "layers":
             base = "bert/encoder/layer_%s/" % p[1]
-            sub = {"qkv": "attention/self/qkv/", "attn_out": "attention/output/dense/",
+            sub = {"attn_out": "attention/output/dense/",
                    "attn_ln": "attention/output/LayerNorm/", "inter": "intermediate/dense/",
                    "out": "output/dense/", "out_ln": "output/LayerNorm/"}[p[2]]
             tf = base + sub + (ln[p[3]] if p[2].endswith("ln") else kb[p[3]])

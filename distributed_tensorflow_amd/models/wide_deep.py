@@ -69,7 +69,8 @@ class _SplitDeepWide(torch.autograd.Function):
 
 class WideDeep(nn.Module):
     def __init__(self, comm=None, device=None, num_features=26, rows_per_table=100000, embedding_dim=64,
-                 dense_features=13, hidden=(1024, 512, 256), emb_optimizer="adagrad", emb_lr=0.05, atomic=False):
+                 dense_features=13, hidden=(1024, 512, 256), emb_optimizer="adagrad", emb_lr=0.05, atomic=False,
+                 partition="mod", route="capacity", capacity_factor=1.25):
         super().__init__()
         comm = comm or Comm.single()
         if isinstance(rows_per_table, (list, tuple)):
@@ -79,7 +80,8 @@ class WideDeep(nn.Module):
         self.num_features, self.embedding_dim = len(rows), int(embedding_dim)
         self.dense_features = int(dense_features)
         self.embeddings = ShardedEmbedding(rows, self.embedding_dim + WIDE_PAD, comm, device, optimizer=emb_optimizer,
-                                           lr=emb_lr, atomic=atomic,
+                                           lr=emb_lr, atomic=atomic, partition=partition, route=route,
+                                           capacity_factor=capacity_factor,
                                            names=["C%d" % (i + 1) for i in range(len(rows))])
         self.embeddings.grad_scale = 1.0 / comm.world_size
         dims = [self.num_features * self.embedding_dim + self.dense_features] + list(hidden)
@@ -106,14 +108,15 @@ class WideDeep(nn.Module):
 
 
 def build(comm=None, device=None, **kw):
-    allowed = ("num_features", "rows_per_table", "embedding_dim", "dense_features", "emb_optimizer", "emb_lr", "atomic")
+    allowed = ("num_features", "rows_per_table", "embedding_dim", "dense_features", "emb_optimizer", "emb_lr", "atomic",
+               "partition", "route", "capacity_factor")
     args = {}
     for k in allowed:
         if k in kw:
             v = kw[k]
             if k in ("num_features", "rows_per_table", "embedding_dim", "dense_features"):
                 v = int(v)
-            elif k == "emb_lr":
+            elif k in ("emb_lr", "capacity_factor"):
                 v = float(v)
             elif k == "atomic":
                 v = str(v).lower() in ("1", "true")

@@ -30,6 +30,8 @@ def _lib():
         hip.declare("dtf_embedding_chunk_rows", [])
         hip.declare("dtf_embedding_plan_scratch_ints", [L], L)
         hip.declare("dtf_embedding_segment_plan", [P, L, I, P, P, P, P, P, P])
+        hip.declare("dtf_embedding_route", [P, L, I, I, L, L, L, P, P, P, P, P, P, P])
+        hip.declare("dtf_route_tile", [])
         _declared = True
     return lib
 
@@ -179,6 +181,65 @@ def embedding_sparse_apply(table, acc, idx, grad, opt="sgd", lr=0.01, eps=1e-10,
     if rc == -31:
         raise ValueError("rowwise_adagrad needs D/8 to divide 64 (D in 8,16,32,...,512)")
     hip.check(rc, "dtf_embedding_sparse_apply")
+
+
+# ---------------------------------------------------------------------------
+# id routing for row-sharded tables (route_kernels.hip)
+# ---------------------------------------------------------------------------
+
+def route_reference(ids, W, cap, div=False, rows_per=0, total_rows=None):
+    """Stable bucket-by-owner split with framework ops (CPU path, test oracle).  Returns
+    ``send_ids [W*cap]`` (local row at the owner, -1 = empty), ``slot [n]`` (slot of request i, -1 = dropped or
+    padding), ``inv [W*cap]`` (request held by a slot, -1 = empty), ``totals [W]``, ``dropped`` (0-dim)."""
+    ids = ids.reshape(-1)
+    n, dev = ids.numel(), ids.device
+    total_rows = int(total_rows if total_rows is not None else (1 << 62))
+    valid = (ids >= 0) & (ids < total_rows)
+    if div:
+        owner = torch.div(ids, rows_per, rounding_mode="floor")
+        local = ids - owner * rows_per
+    else:
+        owner = ids % W
+        local = torch.div(ids, W, rounding_mode="floor")
+    owner = torch.where(valid, owner, torch.full_like(owner, W))
+    onehot = owner.unsqueeze(1) == torch.arange(W, device=dev).unsqueeze(0)          # [n, W]
+    rank = (torch.cumsum(onehot, 0) - 1)[torch.arange(n, device=dev), owner.clamp(max=W - 1)]
+    totals = onehot.sum(0)
+    keep = valid & (rank < cap)
+    slot = torch.where(keep, owner * cap + rank, torch.full_like(owner, -1))
+    send_ids = torch.full((W * cap,), -1, dtype=torch.int64, device=dev)
+    inv = torch.full((W * cap,), -1, dtype=torch.int64, device=dev)
+    send_ids[slot[keep]] = local[keep]
+    inv[slot[keep]] = torch.arange(n, device=dev)[keep]
+    dropped = (totals - cap).clamp(min=0).sum()
+    return send_ids, slot, inv, totals, dropped
+
+
+def embedding_route(ids, W, cap, div=False, rows_per=0, total_rows=None, overflow=None):
+    """Device-side routing of global row ids to their owner ranks with a fixed per-owner capacity: no sort, no
+    host synchronisation; ``overflow`` (int64 [1], device) accumulates the number of dropped requests."""
+    ids = ids.reshape(-1)
+    if not ids.is_cuda:
+        send_ids, slot, inv, totals, dropped = route_reference(ids, W, cap, div, rows_per, total_rows)
+        if overflow is not None:
+            overflow += dropped
+        return send_ids, slot, inv, totals
+    lib = _lib()
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    n, dev = ids.numel(), ids.device
+    tile = int(lib.dtf_route_tile())
+    nblk = (n + tile - 1) // tile
+    hist = torch.empty(max(1, nblk) * W, dtype=torch.int32, device=dev)
+    out = torch.empty(W + 2 * W * cap + n, dtype=torch.int64, device=dev)
+    totals, send_ids, inv, slot = out[:W], out[W:W + W * cap], out[W + W * cap:W + 2 * W * cap], out[W + 2 * W * cap:]
+    if overflow is None:
+        overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+    rc = lib.dtf_embedding_route(hip.ptr(ids), n, int(W), int(bool(div)), int(rows_per),
+                                 int(total_rows if total_rows is not None else (1 << 62)), int(cap), hip.ptr(hist),
+                                 hip.ptr(totals), hip.ptr(send_ids), hip.ptr(slot), hip.ptr(inv), hip.ptr(overflow),
+                                 hip.stream())
+    hip.check(rc, "dtf_embedding_route")
+    return send_ids, slot, inv, totals
 
 
 # ---------------------------------------------------------------------------

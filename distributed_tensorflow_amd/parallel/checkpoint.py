@@ -16,6 +16,15 @@ Files under ``<export>/`` (names follow ``tf.train.Saver``):
     pieces ``(rank, section, element offset, length, offset inside the
     variable)`` -- a variable may straddle shards.  Optimizer slots appear as
     ``<var>/Momentum``, ``<var>/Adam``, ``<var>/Adam_1`` like TF slot variables.
+    The shard bytes are the parameter's STORAGE order; ``shape`` is the logical
+    shape and ``storage_order`` (present when it is not the identity) lists the
+    logical dimensions from slowest to fastest varying -- a channels_last conv
+    filter ``[O, I, H, W]`` is stored ``O, H, W, I`` = ``[0, 2, 3, 1]``.
+    :meth:`CheckpointReader.read` returns the logical tensor; ``restore_ps``
+    converts between layouts, so a checkpoint written by an NHWC GPU job
+    restores into a contiguous CPU model and vice versa.  One torch variable
+    may appear as several TF variables (BERT's packed ``qkv`` ->
+    ``query`` / ``key`` / ``value``): row ranges of the same bytes.
 ``model.ckpt-<step>.replicated``
     non-PS state of the chief (``global_step``, BatchNorm moving statistics).
 ``checkpoint``
@@ -103,18 +112,47 @@ class ShardReader:
         return t
 
 
-def dense_variable_index(layout, tf_names, shapes, slot_names):
+def storage_order(t):
+    """Logical dimensions of a dense tensor from slowest to fastest varying in its storage
+    (identity for a contiguous tensor; ``[0, 2, 3, 1]`` for a channels_last 4-D tensor)."""
+    if t.dim() <= 1 or t.is_contiguous():
+        return list(range(t.dim()))
+    # stable sort by decreasing stride; size-1 dimensions keep their logical position among equals
+    return sorted(range(t.dim()), key=lambda d: (-t.stride(d), d))
+
+
+def _segments(tf_names, slot_name, shape, numel):
+    """``[(variable name, first element, end element, shape)]`` of one torch variable: itself, or the row ranges
+    ``tf_names`` splits it into (``[(tf_name, row0, row1), ...]``)."""
+    spec = tf_names.get(slot_name, slot_name)
+    if isinstance(spec, str):
+        return [(spec, 0, numel, list(shape))]
+    inner = numel // shape[0] if shape and shape[0] else 1
+    return [(n, r0 * inner, r1 * inner, [r1 - r0] + list(shape[1:])) for n, r0, r1 in spec]
+
+
+def dense_variable_index(layout, tf_names, shapes, slot_names, orders=None):
     """Index entries of the dense PS variables of a :class:`FlatLayout`."""
     out = {}
+    orders = orders or {}
     for slot in layout.slots:
-        name = tf_names.get(slot.name, slot.name)
+        shape = list(shapes[slot.name])
         pieces = layout.owner_pieces(slot.index)
-        for sec in ("",) + tuple(slot_names):
-            out[name if sec == "" else "%s/%s" % (name, sec)] = {
-                "dtype": "float32", "shape": list(shapes[slot.name]), "torch_name": slot.name,
-                "pieces": [{"rank": r, "section": sec, "offset": so, "length": ln, "var_offset": vo}
-                           for r, so, vo, ln in pieces],
-            }
+        order = orders.get(slot.name)
+        identity = order is None or list(order) == list(range(len(shape)))
+        segs = _segments(tf_names, slot.name, shape, slot.numel)
+        assert identity or len(segs) == 1, "a variable split into several names must be stored contiguously"
+        for name, lo, hi, sshape in segs:
+            for sec in ("",) + tuple(slot_names):
+                ent = {"dtype": "float32", "shape": sshape, "torch_name": slot.name, "pieces": []}
+                if not identity:
+                    ent["storage_order"] = list(order)
+                for r, so, vo, ln in pieces:
+                    a, b = max(vo, lo), min(vo + ln, hi)
+                    if a < b:
+                        ent["pieces"].append({"rank": r, "section": sec, "offset": so + (a - vo), "length": b - a,
+                                              "var_offset": a - lo})
+                out[name if sec == "" else "%s/%s" % (name, sec)] = ent
     return out
 
 
@@ -196,8 +234,24 @@ class CheckpointReader:
         return out
 
     def read(self, name):
+        """The variable as a LOGICAL tensor of its recorded shape (whatever order its bytes are stored in)."""
         v = self.index["variables"][name]
-        return self.read_flat(name).reshape(v["shape"]) if v["shape"] else self.read_flat(name)[0]
+        if not v["shape"]:
+            return self.read_flat(name)[0]
+        order = v.get("storage_order")
+        if not order or order == list(range(len(v["shape"]))):
+            return self.read_flat(name).reshape(v["shape"])
+        stored = self.read_flat(name).reshape([v["shape"][d] for d in order])
+        inverse = [order.index(d) for d in range(len(order))]
+        return stored.permute(inverse)
+
+    def read_storage(self, name, order):
+        """The variable flattened in the storage order ``order`` (converted when the file's differs)."""
+        v = self.index["variables"][name]
+        have = v.get("storage_order") or list(range(len(v["shape"])))
+        if list(order) == list(have):
+            return self.read_flat(name)
+        return self.read(name).permute(list(order)).contiguous().reshape(-1)
 
     def replicated(self):
         p = os.path.join(self.dir, "%s-%d.replicated" % (PREFIX, self.step))
@@ -238,7 +292,8 @@ def save_ps(ps, export_dir, step=None, tf_names=None, replicated=None, rank=None
     comm.barrier()
     if rank == 0:
         shapes = {n: tuple(p.shape) for n, p in ps.named_params}
-        variables = dense_variable_index(ps.layout, tf_names or {}, shapes, ps.opt.slots)
+        orders = {n: storage_order(p) for n, p in ps.named_params}
+        variables = dense_variable_index(ps.layout, tf_names or {}, shapes, ps.opt.slots, orders)
         if extra_variables:
             variables.update(extra_variables)
         if replicated is not None:
@@ -254,29 +309,46 @@ def save_ps(ps, export_dir, step=None, tf_names=None, replicated=None, rank=None
 
 
 def restore_ps(ps, export_dir, step=None, tf_names=None):
-    """Load master weights + optimizer slots into ``ps`` (any world size), and
+    """Load master weights + optimizer slots into ``ps`` (any world size, bucket size or memory format), and
     refresh the wire-dtype parameters the model reads.  Returns the reader."""
     rd = CheckpointReader(export_dir, step)
     tf_names = tf_names or {}
     L, r = ps.layout, ps.comm.rank
+    hosted = getattr(ps, "hosted", True)
     targets = [("", ps.master)]
     slots = ps.opt.slots
     if len(slots) >= 1 and ps.slot_m is not None:
         targets.append((slots[0], ps.slot_m))
     if len(slots) >= 2 and ps.slot_v is not None:
         targets.append((slots[1], ps.slot_v))
-    for slot in L.slots:
-        name = tf_names.get(slot.name, slot.name)
-        for rank, shard_off, var_off, length in L.owner_pieces(slot.index):
-            if rank != r:
-                continue
-            for sec, dst in targets:
+    for slot, p in zip(L.slots, ps.params):
+        order = storage_order(p)
+        segs = _segments(tf_names, slot.name, list(p.shape), slot.numel)
+        missing = [n for n, _, _, _ in segs if not rd.has(n)]
+        if missing:
+            raise KeyError("checkpoint %s has no variable %s (for %s)" % (export_dir, missing[0], slot.name))
+        cache = {}
+
+        def flat_of(vname, order=order, cache=cache):
+            # the variable in THIS model's storage order; read once, sliced per piece
+            if vname not in cache:
+                cache[vname] = rd.read_storage(vname, order)
+            return cache[vname]
+
+        for sec, dst in targets:
+            for name, lo, hi, _ in segs:
                 vname = name if sec == "" else "%s/%s" % (name, sec)
                 if not rd.has(vname):
                     continue
-                dst[shard_off:shard_off + length].copy_(rd.read_flat(vname, var_off, length))
+                for rank, shard_off, var_off, length in L.owner_pieces(slot.index):
+                    if rank != r or not hosted:
+                        continue
+                    a, b = max(var_off, lo), min(var_off + length, hi)
+                    if a < b:
+                        dst[shard_off + (a - var_off):shard_off + (b - var_off)].copy_(flat_of(vname)[a - lo:b - lo])
         # the full variable, for the local wire-dtype copy the model computes with
-        ps.param_flat[slot.flat_off:slot.flat_off + slot.numel].copy_(rd.read_flat(name))
+        for name, lo, hi, _ in segs:
+            ps.param_flat[slot.flat_off + lo:slot.flat_off + hi].copy_(flat_of(name))
     ps.global_step = rd.step
     if getattr(ps, "hyper", None) is not None:
         ps.hyper[2:3].fill_(float(rd.step + 1))

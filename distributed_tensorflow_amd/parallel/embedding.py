@@ -3,9 +3,11 @@ replaces TF1's PS-hosted partitioned variables with ``mod`` row partitioning,
 external X3, and the ``SparseApply*`` updates on the PS, X4).
 
 All feature tables of a model live in ONE row space (``table_offsets``), sharded
-by ``row % W`` over the W ranks: rank r hosts rows ``r, r+W, r+2W, ...`` as local
-rows ``row // W`` -- TF's ``mod`` partition strategy, and the naming of the
-checkpoint sections follows TF's partitioned variables (``<name>/part_<r>``).
+over the W ranks either by ``row % W`` (rank r hosts rows ``r, r+W, r+2W, ...`` as
+local rows ``row // W`` -- TF's ``mod`` partition strategy, the default: hot ids of
+a skewed distribution spread over all owners) or in contiguous ranges of
+``ceil(rows / W)`` (TF's ``div`` strategy); the naming of the checkpoint sections
+follows TF's partitioned variables (``<name>/part_<r>``).
 Tables are sized for 288 GB of HBM per GPU: a rank's shard (fp32 rows + the
 optimizer accumulator) is one contiguous allocation.
 
@@ -18,6 +20,16 @@ of feature tables::
 The sparse optimizer step is fused into backward on the owning rank (exactly
 where TF1 runs SparseApplyAdagrad: on the PS); the table is not a dense
 ``nn.Parameter`` and never enters the dense push/pull buckets.
+
+Routing never touches the host (``route="capacity"``, the default): a stable
+bucket-by-owner HIP kernel (``ops/csrc/route_kernels.hip``) places request i at
+slot ``owner * cap + rank_i`` of a fixed-capacity send list, so the three
+all-to-alls have constant, equal splits -- no sort, no ``bincount``, no
+``.tolist()``; the rows come back through the same slots and are un-permuted by a
+K3 gather.  ``cap = capacity_factor * N / W`` (MoE-style); requests beyond it are
+dropped and counted on the device, and :meth:`check_overflow` (polled every few
+hundred steps, the only host read) grows the capacity and reports.  ``route="exact"``
+keeps the variable-split exchange (one host sync per step) for debugging.
 """
 from __future__ import annotations
 
@@ -44,7 +56,8 @@ class _Lookup(torch.autograd.Function):
 class ShardedEmbedding(nn.Module):
     def __init__(self, table_rows, dim, comm: Comm = None, device=None, table_dtype=torch.float32,
                  out_dtype=None, optimizer="adagrad", lr=0.01, eps=1e-10, init_std=0.01, atomic=False,
-                 names=None, seed=1234, initial_accumulator=0.1):
+                 names=None, seed=1234, initial_accumulator=0.1, partition="mod", route="capacity",
+                 capacity_factor=1.25, overflow_check_every=200):
         super().__init__()
         self.comm = comm or Comm.single()
         self.dim = int(dim)
@@ -55,8 +68,13 @@ class ShardedEmbedding(nn.Module):
             offs.append(tot)
             tot += r
         self.total_rows = tot
+        assert partition in ("mod", "div") and route in ("capacity", "exact")
+        self.partition, self.route = partition, route
+        self.capacity_factor = float(capacity_factor)
+        self.overflow_check_every = int(overflow_check_every)
         W, r = self.comm.world_size, self.comm.rank
-        self.local_rows = (tot - r + W - 1) // W if tot > r else 0
+        self.rows_per = (tot + W - 1) // W                       # div: rows per part
+        self.local_rows = self.part_rows(r, W)
         device = torch.device(device or self.comm.device)
         self.optimizer, self.lr, self.eps, self.atomic = optimizer, float(lr), float(eps), bool(atomic)
         self.out_dtype = out_dtype or (torch.bfloat16 if device.type == "cuda" else torch.float32)
@@ -77,10 +95,43 @@ class ShardedEmbedding(nn.Module):
             acc = None
         self.register_buffer("accumulator", acc)
         self.register_buffer("table_offsets", torch.tensor(offs, dtype=torch.int64, device=device))
+        self.register_buffer("overflow", torch.zeros(1, dtype=torch.int64, device=device), persistent=False)
         # a dummy tensor that requires grad keeps autograd calling our backward
         self._anchor = nn.Parameter(torch.zeros(1, device=device), requires_grad=True)
         self._anchor.dtf_skip_ps = True
         self.grad_scale = 1.0
+        self._lookups = 0
+        self.dropped_total = 0
+
+    # ------------------------------------------------------------ partition
+    def part_rows(self, k, W=None, strategy=None, total=None):
+        """Rows of the fused row space hosted by part ``k`` of ``W``."""
+        W = W or self.comm.world_size
+        total = self.total_rows if total is None else total
+        if (strategy or self.partition) == "mod":
+            return (total - k + W - 1) // W if total > k else 0
+        per = (total + W - 1) // W
+        return max(0, min(per, total - k * per))
+
+    def global_rows_of(self, k, W=None, strategy=None, lo=0, hi=None, total=None):
+        """Global ids of local rows ``[lo, hi)`` of part ``k`` (a 1-D int64 tensor)."""
+        W = W or self.comm.world_size
+        n = self.part_rows(k, W, strategy, total)
+        hi = n if hi is None else min(hi, n)
+        i = torch.arange(lo, hi, dtype=torch.int64)
+        if (strategy or self.partition) == "mod":
+            return k + W * i
+        total = self.total_rows if total is None else total
+        return k * ((total + W - 1) // W) + i
+
+    def _owner_local(self, g, W=None, strategy=None, total=None):
+        W = W or self.comm.world_size
+        if (strategy or self.partition) == "mod":
+            return g % W, torch.div(g, W, rounding_mode="floor")
+        total = self.total_rows if total is None else total
+        per = (total + W - 1) // W
+        o = torch.div(g, per, rounding_mode="floor")
+        return o, g - o * per
 
     # ------------------------------------------------------------------ API
     def forward(self, ids):
@@ -95,13 +146,36 @@ class ShardedEmbedding(nn.Module):
         """Global row ids ``[n]`` -> ``[n, dim]`` (already offset into the fused row space)."""
         return _Lookup.apply(self._anchor, self, global_rows.reshape(-1))
 
-    # ------------------------------------------------------------ internals
-    def _route(self, flat_ids):
-        """Sort requests by owner rank and exchange the split sizes."""
+    def capacity(self, n):
+        """Slots per (source, owner) pair for ``n`` requests per rank."""
         W = self.comm.world_size
-        dest = flat_ids % W
+        if W == 1:
+            return max(1, n)
+        c = int(n / W * self.capacity_factor) + 1
+        return max(64, min(n, (c + 63) // 64 * 64))
+
+    def check_overflow(self, grow=True):
+        """The only host read of the routed path: requests dropped since the last check.  On overflow the
+        capacity factor grows (x1.5) so that later steps are exact again, and a warning names the loss."""
+        dropped = int(self.overflow.item())
+        if dropped:
+            self.overflow.zero_()
+            self.dropped_total += dropped
+            msg = "[embedding] %d lookups exceeded the all-to-all capacity (factor %.2f) and were dropped" % (
+                dropped, self.capacity_factor)
+            if grow:
+                self.capacity_factor *= 1.5
+                msg += "; capacity factor -> %.2f" % self.capacity_factor
+            print(msg, flush=True)
+        return dropped
+
+    # ------------------------------------------------------------ internals
+    def _route_exact(self, flat_ids):
+        """Sort requests by owner rank and exchange the split sizes (one host sync)."""
+        W = self.comm.world_size
+        dest, local = self._owner_local(flat_ids)
         order = torch.sort(dest, stable=True).indices
-        send_ids = flat_ids[order]
+        send_ids = local[order]
         send_counts = torch.bincount(dest, minlength=W)
         recv_counts = torch.empty_like(send_counts)
         self.comm.all_to_all(recv_counts, send_counts)
@@ -111,27 +185,51 @@ class ShardedEmbedding(nn.Module):
 
     def _forward_impl(self, flat_ids):
         W = self.comm.world_size
-        if W == 1:
+        if W == 1 and not self.comm.live:
             rows = emb_ops.embedding_gather(self.table, flat_ids, self.out_dtype)
-            return rows, (flat_ids, None, None, None)
-        order, send_ids, sc, rc = self._route(flat_ids)
-        recv_ids = torch.empty(sum(rc), dtype=torch.int64, device=flat_ids.device)
-        self.comm.all_to_all(recv_ids, send_ids, rc, sc)
-        local = recv_ids // W
-        rows = emb_ops.embedding_gather(self.table, local, self.out_dtype)
-        back = torch.empty(flat_ids.numel(), self.dim, dtype=self.out_dtype, device=flat_ids.device)
-        self.comm.all_to_all(back, rows, sc, rc)
-        out = torch.empty_like(back)
-        out[order] = back
-        return out, (local, order, sc, rc)
+            return rows, ("local", flat_ids)
+        dev = flat_ids.device
+        if self.route == "exact":
+            order, send_ids, sc, rc = self._route_exact(flat_ids)
+            local = torch.empty(sum(rc), dtype=torch.int64, device=dev)
+            self.comm.all_to_all(local, send_ids, rc, sc)
+            rows = emb_ops.embedding_gather(self.table, local, self.out_dtype)
+            back = torch.empty(flat_ids.numel(), self.dim, dtype=self.out_dtype, device=dev)
+            self.comm.all_to_all(back, rows, sc, rc)
+            out = torch.empty_like(back)
+            out[order] = back
+            return out, ("exact", local, order, sc, rc)
+        # fixed-capacity routed exchange: everything below is device work with constant shapes
+        n = flat_ids.numel()
+        cap = self.capacity(n)
+        send_ids, slot, inv, _ = emb_ops.embedding_route(flat_ids.contiguous(), W, cap, self.partition == "div",
+                                                         self.rows_per, self.total_rows, self.overflow)
+        recv_ids = torch.empty(W * cap, dtype=torch.int64, device=dev)
+        self.comm.all_to_all(recv_ids, send_ids)
+        rows = emb_ops.embedding_gather(self.table, recv_ids, self.out_dtype)          # empty slots -> zero rows
+        back = torch.empty(W * cap, self.dim, dtype=self.out_dtype, device=dev)
+        self.comm.all_to_all(back, rows)
+        out = emb_ops.embedding_gather(back, slot, self.out_dtype)                     # un-permute (dropped -> zeros)
+        self._lookups += 1
+        if self.overflow_check_every and self._lookups % self.overflow_check_every == 0:
+            self.check_overflow()
+        return out, ("routed", recv_ids, inv)
 
     def _backward_impl(self, grad_out, saved):
-        local, order, sc, rc = saved
-        W = self.comm.world_size
-        if W > 1:
+        kind = saved[0]
+        if kind == "local":
+            local = saved[1]
+        elif kind == "exact":
+            _, local, order, sc, rc = saved
             send = grad_out[order].contiguous()
             recv = torch.empty(sum(rc), self.dim, dtype=grad_out.dtype, device=grad_out.device)
             self.comm.all_to_all(recv, send, rc, sc)
+            grad_out = recv
+        else:
+            _, local, inv = saved
+            send = emb_ops.embedding_gather(grad_out, inv, grad_out.dtype)             # slot order, empty -> zeros
+            recv = torch.empty_like(send)
+            self.comm.all_to_all(recv, send)
             grad_out = recv
         emb_ops.embedding_sparse_apply(self.table, self.accumulator, local, grad_out, self.optimizer, self.lr,
                                        self.eps, self.grad_scale, 0.0, 1, self.atomic)
@@ -147,26 +245,69 @@ class ShardedEmbedding(nn.Module):
 
     def checkpoint_variables(self):
         """Index entries (chief): every table is a partitioned variable whose part k is the
-        rows ``k, k+W, ...`` of the fused row space held by rank k."""
+        rows of the fused row space held by rank k (``mod``: ``k, k+W, ...``; ``div``: a contiguous range)."""
         W = self.comm.world_size
         out = {}
         for k in range(W):
-            rows_k = (self.total_rows - k + W - 1) // W if self.total_rows > k else 0
+            rows_k = self.part_rows(k)
+            part = {"strategy": self.partition, "num_parts": W, "part": k, "total_rows": self.total_rows,
+                    "tables": dict(zip(self.names, self.table_rows))}
             out["embeddings/part_%d" % k] = {
                 "dtype": str(self.table.dtype).replace("torch.", ""), "shape": [rows_k, self.dim],
-                "partition": {"strategy": "mod", "num_parts": W, "part": k, "total_rows": self.total_rows,
-                              "tables": dict(zip(self.names, self.table_rows))},
+                "partition": part,
                 "pieces": [{"rank": k, "section": "embeddings/part_%d" % k, "offset": 0,
                             "length": rows_k * self.dim, "var_offset": 0}]}
+            if self.accumulator is not None:
+                width = self.dim if self.accumulator.dim() == 2 else 1
+                out["embeddings/part_%d/Adagrad" % k] = {
+                    "dtype": "float32", "shape": [rows_k, width] if width > 1 else [rows_k], "partition": part,
+                    "pieces": [{"rank": k, "section": "embeddings/part_%d/Adagrad" % k, "offset": 0,
+                                "length": rows_k * width, "var_offset": 0}]}
         return out
+
+    def restore(self, reader, chunk_rows=1 << 20):
+        """Load this rank's rows (table + accumulator) from a checkpoint written with ANY world size and
+        partition strategy: local row i is global row g(i); the old part ``owner_old(g)`` holds it at
+        ``local_old(g)``.  Streams ``chunk_rows`` rows at a time (tables are sized for HBM, not host RAM)."""
+        v0 = reader.index["variables"].get("embeddings/part_0")
+        if v0 is None:
+            raise KeyError("checkpoint has no sharded embedding sections")
+        old = v0["partition"]
+        W_old, strat_old, total_old = int(old["num_parts"]), old.get("strategy", "mod"), int(old["total_rows"])
+        if total_old != self.total_rows:
+            raise ValueError("checkpoint tables have %d rows, the model %d" % (total_old, self.total_rows))
+        r, W = self.comm.rank, self.comm.world_size
+        targets = [("", self.table, self.dim)]
+        if self.accumulator is not None and reader.has("embeddings/part_0/Adagrad"):
+            targets.append(("/Adagrad", self.accumulator, self.dim if self.accumulator.dim() == 2 else 1))
+        same = W_old == W and strat_old == self.partition
+        for lo in range(0, self.local_rows, chunk_rows):
+            hi = min(self.local_rows, lo + chunk_rows)
+            if same:
+                for suffix, dst, width in targets:
+                    flat = reader.read_flat("embeddings/part_%d%s" % (r, suffix), lo * width, (hi - lo) * width)
+                    dst[lo:hi].copy_(flat.view((hi - lo, width) if dst.dim() == 2 else (hi - lo,)))
+                continue
+            g = self.global_rows_of(r, lo=lo, hi=hi)
+            own, loc = self._owner_local(g, W_old, strat_old, total_old)
+            for k in range(W_old):
+                sel = (own == k).nonzero(as_tuple=True)[0]
+                if sel.numel() == 0:
+                    continue
+                lk = loc[sel]
+                a, b = int(lk.min()), int(lk.max()) + 1
+                for suffix, dst, width in targets:
+                    span = reader.read_flat("embeddings/part_%d%s" % (k, suffix), a * width, (b - a) * width)
+                    span = span.view(b - a, width)[lk - a]
+                    dst[lo + sel] = span.to(dst.dtype).to(dst.device) if dst.dim() == 2 else \
+                        span[:, 0].to(dst.dtype).to(dst.device)
 
     def load_rows(self, global_rows, values):
         """Set rows given by GLOBAL ids (only those this rank owns are written)."""
-        W, r = self.comm.world_size, self.comm.rank
-        mine = (global_rows % W) == r
-        self.table[global_rows[mine] // W] = values[mine].to(self.table.dtype)
+        own, loc = self._owner_local(global_rows)
+        mine = own == self.comm.rank
+        self.table[loc[mine]] = values[mine].to(self.table.dtype)
 
     def dense_rows(self, global_rows):
         """Fetch rows by global id from the local shard (debug / tests, W == 1 or owned rows)."""
-        W = self.comm.world_size
-        return self.table[global_rows // W]
+        return self.table[self._owner_local(global_rows)[1]]

@@ -178,9 +178,11 @@ class _Task:
         self.status = {"active": 0, "succeeded": None, "failed": None,
                        "startTime": None, "completionTime": None, "phase": "Pending"}
         self.deleted = False
+        self.released = False      # its GPUs went back to the free list (exactly once)
         self.log_path = None
         self.exit_code = None
-        self.hbm_before = None
+        self.hbm_before = None     # sysfs / rocm-smi counters at start (when the container exposes them)
+        self.hbm_during = None     # one hipMemGetInfo sample while the task runs
 
 
 class LocalCluster:
@@ -206,7 +208,16 @@ class LocalCluster:
         self._events = []     # (rv, type, snapshot)
         self._rv = 0
         self._closed = False
-        self.reclaim_reports = []   # one dict per reaped GPU task
+        self.reclaim_reports = []   # one dict per ended GPU task (success path included)
+        self._max_events = cfg.getint("launcher", "max_events", 4096)
+        self._event_ttl = cfg.getfloat("launcher", "event_ttl_seconds", 600)
+        self._gone = {}             # (ns, name) of deleted jobs -> deletion time (event compaction)
+        # hipMemGetInfo "used" of every device while NO task holds it: what a reclaimed device must return to
+        self._idle_used = {}
+        self._verify = cfg.getboolean("launcher", "verify_reclaim", True) if self._all_gpus else False
+        self._sample_after = cfg.getfloat("launcher", "hbm_sample_after_seconds", 4.0)
+        if self._verify:
+            threading.Thread(target=self._probe_idle_baseline, name="hbm-baseline", daemon=True).start()
 
     # ------------------------------------------------------------------ DNS
     def _alloc_port(self):
@@ -277,7 +288,40 @@ class LocalCluster:
         snap = self._snapshot(t)
         snap["metadata"]["resourceVersion"] = str(self._rv)
         self._events.append((self._rv, typ, snap))
+        if typ == "DELETED":
+            self._gone[(t.namespace, t.name)] = time.time()
+        if len(self._events) > self._max_events:
+            self._compact_events()
         self._cv.notify_all()
+
+    def _compact_events(self):
+        """Bound the event log: events of jobs deleted more than ``event_ttl_seconds`` ago are dropped (every
+        watcher has long seen them); if that is not enough the oldest events go.  Watchers address events by
+        resourceVersion, never by position, so trimming cannot make them skip or repeat."""
+        now = time.time()
+        dead = {k for k, ts in self._gone.items() if now - ts > self._event_ttl}
+        if dead:
+            self._events = [e for e in self._events
+                            if (e[2]["metadata"].get("namespace"), e[2]["metadata"]["name"]) not in dead]
+            for k in dead:
+                self._gone.pop(k, None)
+        if len(self._events) > self._max_events:
+            del self._events[:len(self._events) - self._max_events]
+
+    def _probe_idle_baseline(self):
+        """One hipMemGetInfo probe of the idle devices at service start (a child process; the service never
+        initialises HIP).  A reclaimed device must come back to within ``hbm_reclaim_slack_mb`` of this."""
+        with self._lock:
+            gpus = [g for g in self._all_gpus if g in self._free_gpus]
+        if not gpus:
+            return
+        out = probe_hbm(gpus, self._python)
+        if out:
+            with self._lock:
+                for o in out:
+                    # only trust a baseline measured while the device was still unassigned
+                    if o["gpu"] in self._free_gpus:
+                        self._idle_used.setdefault(o["gpu"], o["used"])
 
     @staticmethod
     def _gpu_request(body, resource_name):
@@ -345,8 +389,6 @@ class LocalCluster:
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
         os.makedirs(self._log_dir, exist_ok=True)
         t.log_path = os.path.join(self._log_dir, t.name + ".log")
-        used = hbm_used_bytes()
-        t.hbm_before = {g: used[g] for g in t.gpus if g < len(used)}
         logf = open(t.log_path, "ab", buffering=0)
         try:
             t.proc = subprocess.Popen(cmd, env=env, stdout=logf, stderr=subprocess.STDOUT,
@@ -363,18 +405,31 @@ class LocalCluster:
             timer.start()
 
     def _reap(self, t):
+        # counters / probes run here, in the task's own waiter thread: never under the cluster lock
+        if t.gpus and self._verify:
+            used = hbm_used_bytes()
+            t.hbm_before = {g: used[g] for g in t.gpus if g < len(used)} or None
+            try:
+                t.proc.wait(self._sample_after)
+            except subprocess.TimeoutExpired:
+                t.hbm_during = probe_hbm(t.gpus, self._python)       # one sample while the task holds the device
         rc = t.proc.wait()
         with self._lock:
             t.exit_code = rc
-            self._release_gpus(t)
             if t.deleted:
-                return
+                return        # delete_namespaced_job owns the rest: kill -> verify -> release, exactly once
             if rc == 0:
                 t.status.update(active=0, succeeded=1, phase="Succeeded", completionTime=time.time())
             else:
                 t.status.update(active=0, failed=1, phase="Failed", completionTime=time.time())
             self._emit("MODIFIED", t)
-            self._schedule()
+        # the devices stay reserved until the probe has seen them WITHOUT a new tenant
+        if t.gpus and self._verify:
+            self._verify_reclaim(t)
+        with self._lock:
+            if not t.deleted:
+                self._release_gpus(t)
+                self._schedule()
 
     def _deadline_exceeded(self, t):
         """activeDeadlineSeconds: a task still running past its deadline is killed and reported
@@ -386,9 +441,14 @@ class LocalCluster:
         self._kill(t)
 
     def _release_gpus(self, t):
+        # caller holds the lock.  Idempotent per task: a second call must not re-add a device that has been
+        # handed to another task in the meantime (double release -> two tenants on one GPU)
+        if t.released:
+            return
+        t.released = True
         for g in t.gpus:
-            if g not in self._free_gpus:
-                self._free_gpus.append(g)
+            assert g not in self._free_gpus, "GPU %d released twice" % g
+            self._free_gpus.append(g)
         self._free_gpus.sort()
 
     def read_namespaced_job(self, name, namespace):
@@ -430,15 +490,19 @@ class LocalCluster:
         return how
 
     def _verify_reclaim(self, t):
-        """After a GPU task was killed: is its HBM back?  Authoritative check = a fresh
-        process asking the driver (``hipMemGetInfo`` through ``torch.cuda.mem_get_info``) on
-        exactly the devices the task held; the sysfs / rocm-smi counters are recorded too when
-        the container exposes them (on some boxes they read 0 whatever is allocated)."""
+        """After a GPU task ended (killed OR finished normally): is its HBM back?  Authoritative check = a fresh
+        process asking the driver (``hipMemGetInfo`` through ``torch.cuda.mem_get_info``) on exactly the devices the
+        task held, compared with what those devices showed when idle (the probe at service start, refreshed by every
+        clean reclaim) + ``hbm_reclaim_slack_mb``.  Called while the devices are still reserved, so no new tenant
+        can be mistaken for a leak.  The sysfs / rocm-smi counters are recorded only when they carry information
+        (on some boxes they read 0 whatever is allocated)."""
         if not t.gpus:
             return None
         slack = self._cfg.getint("launcher", "hbm_reclaim_slack_mb", 64) << 20
-        rep = {"task": t.name, "gpus": list(t.gpus)}
-        if t.hbm_before:
+        rep = {"task": t.name, "gpus": list(t.gpus), "exit_code": t.exit_code}
+        if t.hbm_during:
+            rep["during"] = t.hbm_during
+        if t.hbm_before and any(v > 0 for v in t.hbm_before.values()):
             deadline = time.time() + 5.0
             while True:
                 used = hbm_used_bytes()
@@ -450,10 +514,25 @@ class LocalCluster:
             rep.update(counter_before=t.hbm_before, counter_after=after, counter_ok=ok)
         probe = probe_hbm(t.gpus, self._python)
         if probe is not None:
-            # a context-less device shows only the driver's own reservation as used
-            limit = max(slack, 2 << 30)
             rep["probe"] = probe
-            rep["reclaimed"] = all(p["used"] <= limit for p in probe)
+            with self._lock:
+                base = {p["gpu"]: self._idle_used.get(p["gpu"]) for p in probe}
+            rep["idle_baseline"] = base
+            checks = []
+            for p in probe:
+                b = base.get(p["gpu"])
+                if b is None:
+                    # no idle baseline (service started with the device busy): fall back to "far below what the
+                    # task held" when a during-sample exists, else to the driver-reservation bound
+                    held = next((d["used"] for d in (t.hbm_during or []) if d.get("gpu") == p["gpu"]), None)
+                    checks.append(p["used"] <= (min(held // 4, 2 << 30) if held else (2 << 30)))
+                else:
+                    checks.append(p["used"] <= b + slack)
+            rep["reclaimed"] = all(checks)
+            if rep["reclaimed"]:
+                with self._lock:
+                    for p in probe:
+                        self._idle_used[p["gpu"]] = min(p["used"], self._idle_used.get(p["gpu"], p["used"]))
         else:
             rep["reclaimed"] = rep.get("counter_ok")
         self.reclaim_reports.append(rep)
@@ -465,9 +544,14 @@ class LocalCluster:
             t = self._jobs.get((namespace, name))
             if t is None:
                 raise ApiException(404, "job %s not found" % name)
+            already = t.deleted
             t.deleted = True
+            released = t.released
+        if already:
+            raise ApiException(409, "job %s is already being deleted" % name)
         how = self._kill(t)
-        rep = self._verify_reclaim(t)
+        # a task that ended on its own has been verified by its waiter thread already
+        rep = self._verify_reclaim(t) if (self._verify and not released and t.gpus) else None
         with self._lock:
             self._jobs.pop((namespace, name), None)
             self._release_gpus(t)
@@ -485,26 +569,29 @@ class LocalCluster:
         (the reference's ``timeout_seconds=0``)."""
         rv = int(resource_version)
         deadline = None if timeout is None else time.monotonic() + timeout
-        idx = 0
         while True:
-            batch = []
             with self._cv:
-                while idx < len(self._events) and self._events[idx][0] <= rv:
-                    idx += 1
-                if idx >= len(self._events):
+                batch = self._newer_than(rv)
+                if not batch:
                     if self._closed or (stop is not None and stop.is_set()):
                         return
                     left = 0.25 if deadline is None else min(0.25, deadline - time.monotonic())
                     if left <= 0:
                         return
                     self._cv.wait(left)
-                batch = self._events[idx:]
-                idx = len(self._events)
+                    batch = self._newer_than(rv)
             for erv, typ, snap in batch:
+                rv = erv
                 if snap["metadata"].get("namespace") != namespace:
                     continue
-                rv = erv
                 yield {"type": typ, "object": AttrDict.wrap(copy.deepcopy(snap))}
+
+    def _newer_than(self, rv):
+        # caller holds the lock; events are sorted by resourceVersion (the log may have been compacted)
+        import bisect
+
+        i = bisect.bisect_right(self._events, rv, key=lambda e: e[0])
+        return self._events[i:]
 
     def events_since(self, namespace, resource_version=0, wait=0.0):
         """Non-generator form used by the HTTP API (long poll)."""

@@ -99,6 +99,21 @@ def save_checkpoint(model, ps, export, step, tf_names, chief):
                         extra_sections=sections or None, extra_variables=variables or None)
 
 
+def restore_checkpoint(model, ps, export, tf_names):
+    """Resume: dense PS state (any world size), replicated buffers, and the row-sharded embedding tables with
+    their accumulators (re-partitioned when the world size or the partition strategy changed).  Returns the step."""
+    rd = ckpt.restore_ps(ps, export, tf_names=tf_names)
+    rep = rd.replicated()
+    skip = tuple(n + "." for n, _ in _embedding_modules(model))
+    with torch.no_grad():
+        for n, b in model.named_buffers():
+            if n in rep and not (skip and n.startswith(skip)):
+                b.copy_(rep[n])
+        for _, m in _embedding_modules(model):
+            m.restore(rd)
+    return rd.step
+
+
 def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=None, on_step=None,
                items_per_step=None, start_step=0):
     """Runs ``steps`` PS steps; returns (last_loss, seconds, steps_done)."""
@@ -184,13 +199,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     tf_names = mod.tf_variable_names(model) if hasattr(mod, "tf_variable_names") else {}
     start_step = 0
     if opts.resume and do_ckpt and placement != "dedicated" and ckpt.latest_step(export) is not None:
-        rd = ckpt.restore_ps(ps, export, tf_names=tf_names)
-        rep = rd.replicated()
-        with torch.no_grad():
-            for n, b in model.named_buffers():
-                if n in rep:
-                    b.copy_(rep[n])
-        start_step = rd.step
+        start_step = restore_checkpoint(model, ps, export, tf_names)
         print("[worker %d] resumed from step %d" % (task_index, start_step), flush=True)
     bkw = {k: int(v) for k, v in opts.extra.items() if k in ("seq_len", "image_size")}
     if getattr(mod, "NEEDS_COMM", False):

@@ -14,42 +14,62 @@ from distributed_tensorflow_amd.parallel.comm import Comm  # noqa: E402
 from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec, ShardedPS  # noqa: E402
 
 
-def widedeep_case(comm, out_dir):
-    """Row-sharded embeddings over W ranks == the same model on one rank with the whole batch."""
+def widedeep_case(comm, out_dir, case="widedeep"):
+    """Row-sharded embeddings over W ranks == the same model on one rank with the whole batch.
+    Variants: ``_div`` (contiguous-range partition), ``_exact`` (variable-split exchange), ``_tight`` (capacity
+    factor 1.0: overflow must be counted and reported), ``_save`` / ``_resume[_div]`` (checkpoint at step 3, resume on
+    another world size / partition strategy)."""
     from distributed_tensorflow_amd.models import wide_deep as wd
+    from distributed_tensorflow_amd.train import trainer
 
     r, W = comm.rank, comm.world_size
     torch.manual_seed(5)
     kw = dict(num_features=4, rows_per_table=97, embedding_dim=8, emb_optimizer="adagrad", emb_lr=0.1)
-    model = wd.build(comm=comm, device="cpu", **kw)
+    model = wd.build(comm=comm, device="cpu", partition="div" if "div" in case else "mod", **kw)
+    emb = model.embeddings
+    if "exact" in case:
+        emb.route = "exact"
+    if "tight" in case:
+        emb.capacity_factor, emb.overflow_check_every = 0.5, 0
     # W-independent table init: the same global rows everywhere
     g = torch.Generator().manual_seed(99)
-    rows = torch.arange(model.embeddings.total_rows)
-    vals = torch.randn(model.embeddings.total_rows, model.embeddings.dim, generator=g) * 0.05
-    model.embeddings.load_rows(rows, vals)
+    rows = torch.arange(emb.total_rows)
+    vals = torch.randn(emb.total_rows, emb.dim, generator=g) * 0.05
+    emb.load_rows(rows, vals)
     ps = ShardedPS(list(model.named_parameters()), comm, OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9),
                    bucket_mb=0.01, wire_dtype=torch.float32)
+    tf_names = wd.tf_variable_names(model)
     ids, dense, y = wd.synthetic_batch(64, seed=21, model=model)
     per = 64 // W
     sl = slice(r * per, (r + 1) * per)
     batch = (ids[sl], dense[sl], y[sl])
     losses = []
-    for _ in range(5):
+    start, steps = 0, 5
+    ck = os.path.join(out_dir, "ckpt_wd")
+    if "resume" in case:
+        start = trainer.restore_checkpoint(model, ps, ck, tf_names)
+    for it in range(start, steps):
         loss = wd.loss_fn(model, batch)
         loss.backward()
         ps.step()
         losses.append(float(loss.detach()))
+        if "save" in case and it + 1 == 3:
+            trainer.save_checkpoint(model, ps, ck, it + 1, tf_names, r == 0)
+    dropped = emb.check_overflow(grow=False) if emb.route == "capacity" else 0
     # reassemble the full table on every rank
-    full = torch.zeros(model.embeddings.total_rows, model.embeddings.dim)
-    mine = torch.arange(r, model.embeddings.total_rows, W)
-    full[mine] = model.embeddings.table
+    full = torch.zeros(emb.total_rows, emb.dim)
+    acc = torch.zeros(emb.total_rows, emb.dim)
+    mine = emb.global_rows_of(r)
+    full[mine] = emb.table
+    acc[mine] = emb.accumulator
     import torch.distributed as dist
     if W > 1:
         dist.all_reduce(full)
+        dist.all_reduce(acc)
     dense_full = ps.full_master()
     if r == 0:
-        torch.save({"table": full, "dense": dense_full, "losses": losses},
-                   os.path.join(out_dir, "result_widedeep_w%d.pt" % W))
+        torch.save({"table": full, "acc": acc, "dense": dense_full, "losses": losses, "dropped": dropped},
+                   os.path.join(out_dir, "result_%s_w%d.pt" % (case, W)))
     comm.barrier()
     comm.close()
 
@@ -106,8 +126,8 @@ def main():
     case, out_dir = sys.argv[1], sys.argv[2]
     comm = Comm.from_env(torch.device("cpu"), backend="gloo")
     r, W = comm.rank, comm.world_size
-    if case == "widedeep":
-        return widedeep_case(comm, out_dir)
+    if case.startswith("widedeep"):
+        return widedeep_case(comm, out_dir, case)
     if case.startswith("real_"):
         return real_layout_case(comm, out_dir, case)
     torch.manual_seed(7)   # same init everywhere; broadcast_init also enforces it

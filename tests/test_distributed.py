@@ -140,11 +140,34 @@ def test_checkpoint_resharding_2_to_4_ranks(tmp_path):
         torch.testing.assert_close(resumed["params"][n], p, rtol=1e-5, atol=1e-6)
 
 
-def test_sharded_embedding_equals_single_rank(tmp_path):
+@pytest.mark.parametrize("case,world", [("widedeep", 2), ("widedeep", 4), ("widedeep_div", 2), ("widedeep_exact", 2)])
+def test_sharded_embedding_equals_single_rank(tmp_path, case, world):
     """Config #3 plumbing: ids all-to-all -> owner gather -> rows all-to-all; backward:
-    row grads all-to-all -> sort/segment sparse Adagrad on the owner."""
+    row grads all-to-all -> sort/segment sparse Adagrad on the owner.  Default route = fixed-capacity,
+    device-side bucket-by-owner (no host sync); ``_exact`` = variable splits; ``_div`` = range partition."""
     one = run_ranks(1, "widedeep", tmp_path)
-    two = run_ranks(2, "widedeep", tmp_path)
-    torch.testing.assert_close(two["table"], one["table"], rtol=1e-4, atol=1e-6)
-    torch.testing.assert_close(two["dense"][: one["dense"].numel()].sum(), one["dense"].sum(), rtol=1e-3, atol=1e-3)
+    many = run_ranks(world, case, tmp_path)
+    assert many["dropped"] == 0
+    torch.testing.assert_close(many["table"], one["table"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(many["acc"], one["acc"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(many["dense"][: one["dense"].numel()].sum(), one["dense"].sum(), rtol=1e-3, atol=1e-3)
     assert one["losses"][-1] < one["losses"][0]
+
+
+def test_embedding_capacity_overflow_is_counted(tmp_path):
+    """A capacity factor below 1 must drop lookups, count them on the device and report them (never silently)."""
+    res = run_ranks(2, "widedeep_tight", tmp_path)
+    assert res["dropped"] > 0
+
+
+@pytest.mark.parametrize("resume_case,world", [("widedeep_resume", 4), ("widedeep_resume_div", 2), ("widedeep_resume", 1)])
+def test_embedding_checkpoint_resume_repartitions(tmp_path, resume_case, world):
+    """Save at step 3 on 2 ranks (mod partition); resume on 4 ranks / on 2 ranks with the div partition / on 1 rank:
+    tables AND Adagrad accumulators are re-partitioned row by row, and the finished run equals the uninterrupted one
+    (resume used to restart from freshly initialised tables)."""
+    full = run_ranks(2, "widedeep_save", tmp_path)
+    resumed = run_ranks(world, resume_case, tmp_path)
+    assert len(resumed["losses"]) == 2
+    torch.testing.assert_close(resumed["table"], full["table"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(resumed["acc"], full["acc"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(resumed["dense"][: full["dense"].numel()].sum(), full["dense"].sum(), rtol=1e-4, atol=1e-4)

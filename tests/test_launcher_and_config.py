@@ -28,10 +28,109 @@ def _wait(cond, timeout=10.0):
 def cluster(tmp_path):
     ApiConfig.override("image", "tensorflow", "tests.fake_task")
     ApiConfig.override("launcher", "grace_seconds", "0.3")
+    ApiConfig.override("launcher", "verify_reclaim", "0")        # no real devices here
     c = LocalCluster(gpus=[0, 1], log_dir=str(tmp_path), extra_env={"PYTHONPATH": ROOT})
-    c._verify_reclaim = lambda t: None        # no real devices here
     yield c
     c.shutdown()
+    ApiConfig.override("launcher", "verify_reclaim", "1")
+
+
+@pytest.fixture
+def probing_cluster(tmp_path, monkeypatch):
+    """Two fake devices with the HBM verification ON, the hipMemGetInfo child replaced by a slow fake: the window
+    between 'task killed' and 'devices released' is then wide enough to race against."""
+    from distributed_tensorflow_amd.service import launcher as L
+
+    calls = []
+
+    def fake_probe(gpus, python=None, timeout=90):
+        calls.append(list(gpus))
+        time.sleep(0.4)
+        return [{"gpu": g, "free": 1000, "total": 1100, "used": 100} for g in gpus]
+
+    monkeypatch.setattr(L, "probe_hbm", fake_probe)
+    monkeypatch.setattr(L, "hbm_used_bytes", lambda: [])
+    ApiConfig.override("image", "tensorflow", "tests.fake_task")
+    ApiConfig.override("launcher", "grace_seconds", "0.3")
+    ApiConfig.override("launcher", "verify_reclaim", "1")
+    ApiConfig.override("launcher", "hbm_sample_after_seconds", "0.2")
+    c = LocalCluster(gpus=[0, 1], log_dir=str(tmp_path), extra_env={"PYTHONPATH": ROOT})
+    c.probe_calls = calls
+    yield c
+    c.shutdown()
+
+
+def _holders(cluster):
+    """device -> names of the tasks that currently hold it (running or being verified)."""
+    out = {}
+    with cluster._lock:
+        for t in cluster._jobs.values():
+            if t.gpus and not t.released:
+                for g in t.gpus:
+                    out.setdefault(g, []).append(t.name)
+        free = list(cluster._free_gpus)
+    return out, free
+
+
+def test_delete_while_creating_never_double_allocates_a_gpu(probing_cluster):
+    """cancel a job and resubmit at once.  The killed task's devices must stay reserved until its HBM
+    probe is over and go back to the free list exactly once -- no device may ever have two tenants, nor be free
+    while held."""
+    import threading
+
+    c = probing_cluster
+    bad = []
+    stop = threading.Event()
+
+    def invariant():
+        while not stop.is_set():
+            held, free = _holders(c)
+            for g, names in held.items():
+                if len(names) > 1 or g in free:
+                    bad.append((g, names, free))
+            if len(set(free)) != len(free):
+                bad.append(("dup-free", free))
+            time.sleep(0.002)
+
+    th = threading.Thread(target=invariant, daemon=True)
+    th.start()
+    for rnd in range(3):
+        a = c.create_namespaced_job("default", _job(4 * rnd + 0, 99, 1, "sleep:30"))
+        b = c.create_namespaced_job("default", _job(4 * rnd + 1, 99, 1, "sleep:30"))
+        assert sorted(a["status"]["gpus"] + b["status"]["gpus"]) == [0, 1]
+        deleters = [threading.Thread(target=c.delete_namespaced_job, args=(j["metadata"]["name"], "default"))
+                    for j in (a, b)]
+        for d in deleters:
+            d.start()
+        # resubmit while the kills / probes are in flight: must stay Pending until a device is REALLY back
+        n1 = c.create_namespaced_job("default", _job(4 * rnd + 2, 99, 1, "sleep:0.2"))
+        n2 = c.create_namespaced_job("default", _job(4 * rnd + 3, 99, 1, "sleep:0.2"))
+        for d in deleters:
+            d.join()
+        assert _wait(lambda: all(c.read_namespaced_job(j["metadata"]["name"], "default")["status"]["succeeded"] == 1
+                                 for j in (n1, n2)), 20)
+        assert _wait(lambda: c.free_gpus() == [0, 1], 10)
+    stop.set()
+    th.join()
+    assert not bad, bad[:5]
+    # every ended GPU task was probed (killed ones by delete, finished ones by their waiter thread)
+    reps = c.reclaim_reports
+    assert len(reps) == 12 and all(r["reclaimed"] for r in reps)
+    assert any("during" in r for r in reps)
+
+
+def test_event_log_is_bounded(cluster):
+    cluster._max_events, cluster._event_ttl = 40, 0.0
+    for i in range(30):
+        j = cluster.create_namespaced_job("default", _job(i, 77, 0, "exit:0"))
+        name = j["metadata"]["name"]
+        assert _wait(lambda: cluster.read_namespaced_job(name, "default")["status"]["succeeded"] == 1)
+        cluster.delete_namespaced_job(name, "default")
+    assert len(cluster._events) <= 41
+    # a watcher that resumes from an old resourceVersion neither crashes nor repeats events
+    evs = list(cluster.watch("default", 5, timeout=0.2))
+    rvs = [int(e["object"]["metadata"]["resourceVersion"]) for e in evs]
+    assert rvs == sorted(set(rvs)) and all(r > 5 for r in rvs)
 
 
 def _job(seq, count, gpu, file_field="sleep:0.4"):
