@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0: 256 for resnet, model default otherwise)")
     ap.add_argument("--model-arg", action="append", default=[], help="key=value forwarded to the model's build()")
     ap.add_argument("--image-size", type=int, default=0, help="0: model default (224 / 299)")
-    ap.add_argument("--update-mode", default="sync", choices=["sync", "stale"])
+    ap.add_argument("--update-mode", default="sync", choices=["sync", "stale", "async"],
+                    help="async: one-sided applies over peer-mapped PS shards, no collective in the step")
     ap.add_argument("--staleness", type=int, default=1, help="stale mode: updates become visible this many steps late")
     ap.add_argument("--wire-dtype", default="auto", choices=["auto", "bf16", "fp32"],
                     help="dtype of the gradient / parameter traffic (auto: bf16 on GPU, fp32 on CPU)")
@@ -115,9 +116,15 @@ def main():
     model = mod.prepare(model, dev) if hasattr(mod, "prepare") else model.to(dev)
     model.train()
     opt = mod.default_optimizer()
-    ps = ShardedPS(list(model.named_parameters()), comm, opt, bucket_mb=a.bucket_mb,
-                   update_mode=a.update_mode, push=a.push, num_shards=a.num_ps or None, staleness=a.staleness,
-                   wire_dtype={"bf16": torch.bfloat16, "fp32": torch.float32}.get(a.wire_dtype))
+    wire = {"bf16": torch.bfloat16, "fp32": torch.float32}.get(a.wire_dtype)
+    if a.update_mode == "async":
+        from distributed_tensorflow_amd.parallel.async_ps import AsyncPS
+
+        ps = AsyncPS(list(model.named_parameters()), comm, opt, bucket_mb=a.bucket_mb, wire_dtype=wire)
+    else:
+        ps = ShardedPS(list(model.named_parameters()), comm, opt, bucket_mb=a.bucket_mb,
+                       update_mode=a.update_mode, push=a.push, num_shards=a.num_ps or None,
+                       staleness=a.staleness, wire_dtype=wire)
     bkw = {"image_size": a.image_size} if a.image_size else {}
     if getattr(mod, "NEEDS_COMM", False):
         bkw["model"] = model
@@ -132,8 +139,11 @@ def main():
         return loss
 
     graph = None
-    if a.graph and comm.world_size == 1 and on_gpu:
-        # warm up eagerly on a side stream (MIOpen find, allocator), then capture
+    if a.graph and on_gpu:
+        # Whole-step hipGraph: forward + backward + the PS pipeline (bucket packs, RCCL collectives on the comm
+        # stream forked from the backward hooks, shard applies) become ONE graph launch per step -- the ~600 kernel
+        # launches of a step cost the host 18 ms otherwise.  Warm up eagerly on a side stream first (MIOpen kernel
+        # selection, allocator, RCCL channel setup must not happen inside the capture), then capture one step.
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -141,16 +151,32 @@ def main():
                 step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        ps.remove_hooks()
-        ps.overlap = False
-        ps.comm_stream = None
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
+        comm.barrier()
+        torch.cuda.synchronize()
+        # RCCL's watchdog thread polls the events of the warm-up collectives; an event query from ANY thread is
+        # illegal while a global-mode capture is open.  Let it retire them, and capture in thread-local mode.
+        time.sleep(0.5)
+        ok = torch.ones(1, device=dev)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                static_loss = step()
+            graph = g
+        except Exception as e:       # noqa: BLE001 -- any capture failure means "run eagerly", never a dead bench
+            print("[bench] rank %d: hipGraph capture failed (%s: %s); running eagerly" % (
+                comm.rank, type(e).__name__, str(e).splitlines()[0] if str(e) else ""), file=sys.stderr, flush=True)
+            ok.zero_()
+            torch.cuda.synchronize()
+        if comm.world_size > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank replays, or none does
+        if float(ok.item()) < 1.0:
+            graph = None
+        if graph is not None:
+            eager_step = step
 
-        def step():  # noqa: F811
-            graph.replay()
-            return static_loss
+            def step():  # noqa: F811
+                graph.replay()
+                return static_loss
     t_w = time.perf_counter()
     for i in range(a.warmup):
         loss = step()
@@ -168,6 +194,16 @@ def main():
     comm.barrier()
     dev_sync()
     dt = time.perf_counter() - t0
+    # host cost of one step with an EMPTY device queue (outside the timed region): in the timed loop the enqueue of
+    # a graph replay or of a GPU-bound eager step also contains queue back-pressure
+    probe = []
+    for _ in range(3):
+        dev_sync()
+        tp = time.perf_counter()
+        step()
+        probe.append(time.perf_counter() - tp)
+    dev_sync()
+    t_probe = sorted(probe)[1]
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if comm.world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -192,11 +228,14 @@ def main():
                        "update_mode": a.update_mode, "optimizer": opt.kind, "bucket_mb": a.bucket_mb,
                        "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db),
                        "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),
-                       "host_enqueue_ms_per_step": round(t_host / a.steps * 1e3, 3),
+                       "host_enqueue_ms_per_step": round(t_probe * 1e3, 3),
+                       "host_loop_ms_per_step": round(t_host / a.steps * 1e3, 3),
                        "final_loss": round(last_loss, 4)},
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if a.update_mode == "async":
+        ps.close()
     comm.close()
 
 

@@ -172,6 +172,16 @@ def write_index(export_dir, step, world, variables, extra=None):
     return p
 
 
+def write_replicated(export_dir, step, replicated):
+    """Non-PS state of the chief (``global_step``, BatchNorm moving statistics): atomic write."""
+    os.makedirs(export_dir, exist_ok=True)
+    rp = os.path.join(export_dir, "%s-%d.replicated" % (PREFIX, step))
+    torch.save({k: (v.detach().cpu() if isinstance(v, torch.Tensor) else torch.tensor(v))
+                for k, v in replicated.items()}, rp + ".tmp")
+    os.replace(rp + ".tmp", rp)
+    return rp
+
+
 def latest_step(export_dir):
     p = os.path.join(export_dir, "checkpoint")
     if not os.path.isfile(p):
@@ -297,10 +307,7 @@ def save_ps(ps, export_dir, step=None, tf_names=None, replicated=None, rank=None
         if extra_variables:
             variables.update(extra_variables)
         if replicated is not None:
-            rp = os.path.join(export_dir, "%s-%d.replicated" % (PREFIX, step))
-            torch.save({k: (v.detach().cpu() if isinstance(v, torch.Tensor) else torch.tensor(v))
-                        for k, v in replicated.items()}, rp + ".tmp")
-            os.replace(rp + ".tmp", rp)
+            write_replicated(export_dir, step, replicated)
         write_index(export_dir, step, world, variables,
                     extra={"optimizer": ps.opt.kind, "layout": {"total": ps.layout.total,
                                                                 "buckets": len(ps.layout.buckets)}})

@@ -115,13 +115,20 @@ class Comm:
     def send(self, t, dst, tag=0):
         return dist.send(t, self._global(dst), group=self.group, tag=tag)
 
+    def isend(self, t, dst, tag=0):
+        return dist.isend(t, self._global(dst), group=self.group, tag=tag)
+
+    def irecv(self, t, src, tag=0):
+        """Posted receive from ONE peer (works on RCCL and gloo; ``recv(src=None)`` is gloo-only)."""
+        return dist.irecv(t, self._global(src), group=self.group, tag=tag)
+
     def recv(self, t, src=None, tag=0):
         r = dist.recv(t, None if src is None else self._global(src), group=self.group, tag=tag)
         return self._local(r)
 
     def barrier(self):
         if self.live:
-            if self.device.type == "cuda":
+            if self.device.type == "cuda" and "nccl" in str(self.backend):
                 dist.barrier(group=self.group, device_ids=[self.device.index])
             else:
                 dist.barrier(group=self.group)

@@ -14,10 +14,13 @@ sync   (``SyncReplicasOptimizer`` semantics): per step one control all-reduce
        gradient slices (PS ranks add zeros) -> shard apply on the PS ->
        ``broadcast(src=j)`` of the updated slice.
 async  (TF1 default): each worker talks to every PS point-to-point on its own
-       clock: ``send(header) ; send(grad slice)`` then ``recv(updated slice)``;
+       clock: ``send(grad slice + [flag, step])`` then ``recv(updated slice)``;
        the PS applies each worker's gradient the moment it arrives (no
-       averaging, no barrier), serving workers in arrival order
-       (``recv(src=ANY)``, available on gloo).
+       averaging, no barrier).  The PS keeps ONE posted ``irecv`` per worker and
+       polls the requests, serving workers in arrival order: no ``recv(src=ANY)``
+       (which only gloo has), so the same loop runs over RCCL when the PS tasks
+       own GPUs (``resource.ps_gpu``) -- there every peer pair has its own
+       communicator stream, and a worker that has not sent yet blocks nobody.
 When every worker has signalled done the PS leaves its loop, optionally writes
 its checkpoint shard, and blocks until it is killed.
 """
@@ -117,22 +120,48 @@ class PSServer(_Base):
                         self.comm.broadcast(g, j)
             self.global_step += 1
 
-    def _serve_async(self):
-        L = self.layout
-        n = L.shard_total
-        hdr = torch.zeros(2, dtype=torch.float32, device=self.device)
-        g = torch.zeros(n, dtype=self.wire_dtype, device=self.device)
-        done = 0
-        while done < self.W:
-            src = self.comm.recv(hdr, None, tag=1)
-            if hdr[0].item() == DONE:
-                done += 1
-                continue
-            self.comm.recv(g, src, tag=2)
-            _apply(self.opt, g, self.master, self.slot_m, self.slot_v, self.wire, self.lr,
-                   self.global_step + 1)
-            self.global_step += 1
-            self.comm.send(self.wire, src, tag=3)
+    def _serve_async(self, poll_s=50e-6):
+        import time
+
+        n = self.layout.shard_total
+        W, P = self.W, self.P
+        inbox = [torch.zeros(n + 2, dtype=self.wire_dtype, device=self.device) for _ in range(W)]
+        outbox = [torch.zeros(n, dtype=self.wire_dtype, device=self.device) for _ in range(W)]
+        recv = [self.comm.irecv(inbox[w], P + w, tag=2) for w in range(W)]
+        sent = [None] * W
+        live = W
+        while live:
+            progressed = False
+            for w in range(W):
+                req = recv[w]
+                if req is None or not req.is_completed():
+                    continue
+                req.wait()                          # orders the device work after the receive (RCCL); no-op on gloo
+                progressed = True
+                if float(inbox[w][n].item()) == DONE:
+                    recv[w] = None
+                    live -= 1
+                    continue
+                _apply(self.opt, inbox[w][:n], self.master, self.slot_m, self.slot_v, self.wire, self.lr,
+                       self.global_step + 1)
+                self.global_step += 1
+                if sent[w] is not None:
+                    sent[w].wait()                  # the previous reply to this worker has left its buffer
+                outbox[w].copy_(self.wire)
+                sent[w] = self.comm.isend(outbox[w], P + w, tag=3)
+                recv[w] = self.comm.irecv(inbox[w], P + w, tag=2)
+            if not progressed:
+                time.sleep(poll_s)
+        for h in sent:
+            if h is not None:
+                h.wait()
+
+
+def agree_on_step(comm, mine):
+    """Everyone learns the number of applies the PS tasks performed (workers pass 0)."""
+    t = torch.tensor([float(mine)], dtype=torch.float32, device=comm.device if comm.backend == "nccl" else "cpu")
+    comm.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return int(t.item())
 
 
 class PSWorkerClient(_Base):
@@ -192,10 +221,9 @@ class PSWorkerClient(_Base):
         L = self.layout
         if self.update_mode == "async":
             self._pack_all(1.0)
-            hdr = torch.tensor([PUSH, float(self.global_step)], dtype=torch.float32, device=self.device)
+            tail = torch.tensor([PUSH, 0.0], dtype=self.wire_dtype, device=self.device)
             for j in range(self.P):
-                self.comm.send(hdr, j, tag=1)
-                self.comm.send(self._shard_view(self.grad_flat, j), j, tag=2)
+                self.comm.send(torch.cat([self._shard_view(self.grad_flat, j), tail]), j, tag=2)
             for j in range(self.P):
                 buf = torch.empty(L.shard_total, dtype=self.wire_dtype, device=self.device)
                 self.comm.recv(buf, j, tag=3)
@@ -232,12 +260,14 @@ class PSWorkerClient(_Base):
         """Tell the PS tasks this worker is done (the 'signal from worker' the
         reference's comment at ``eventHandlers/CleanJobHandler.py:42`` alludes to)."""
         if self.update_mode == "async":
-            hdr = torch.tensor([DONE, 0.0], dtype=torch.float32, device=self.device)
+            msg = torch.zeros(self.layout.shard_total + 2, dtype=self.wire_dtype, device=self.device)
+            msg[-2] = DONE
             for j in range(self.P):
-                self.comm.send(hdr, j, tag=1)
+                self.comm.send(msg, j, tag=2)
         else:
             ctrl = torch.tensor([1.0, 1.0], dtype=torch.float32, device=self.device)
             self.comm.all_reduce(ctrl)
+        return agree_on_step(self.comm, 0)
 
     def flush(self):
         pass

@@ -58,6 +58,25 @@ def ps_join_forever():
         signal.pause()
 
 
+def resolve_placement(requested, num_ps, env):
+    """One answer per JOB: every task (ps and worker alike) derives it from the job-level facts the manifest
+    exports (``DTF_JOB_WORKER_GPUS`` / ``DTF_JOB_PS_GPUS`` = ``resource.gpu`` / ``resource.ps_gpu``), never from
+    its own device count -- a ps task without a GPU used to pick 'dedicated' while its workers picked 'colocated'
+    and then waited 600 s for a rendezvous that could not happen.
+
+    auto: GPU workers and no GPUs for the ps tasks -> colocated (every GPU rank is worker + PS shard host);
+          ps tasks with their own GPUs, or a CPU job with ps tasks -> dedicated."""
+    if requested in ("colocated", "dedicated"):
+        return requested
+    wg = int(env.get("DTF_JOB_WORKER_GPUS", env.get("DTF_NUM_GPUS", "0")) or 0)
+    pg = int(env.get("DTF_JOB_PS_GPUS", "0") or 0)
+    if num_ps < 1:
+        return "colocated"
+    if wg > 0 and pg == 0:
+        return "colocated"
+    return "dedicated"
+
+
 def main(argv=None):
     t_start = time.time()
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -106,13 +125,8 @@ def main(argv=None):
         return 0
 
     opts = spec
-    num_gpus = int(os.environ.get("DTF_NUM_GPUS", "0"))
-    placement = opts.placement
-    if placement == "auto":
-        placement = "colocated" if (num_gpus > 0 or not ps_hosts) else "dedicated"
-    if opts.update_mode == "async" and placement == "colocated":
-        opts.update_mode = "stale"      # collective counterpart of the async update
     P, W = len(ps_hosts), len(worker_hosts)
+    placement = resolve_placement(opts.placement, P, os.environ)
 
     if placement == "colocated":
         if job_name == "ps":

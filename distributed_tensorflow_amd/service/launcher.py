@@ -376,6 +376,8 @@ class LocalCluster:
         cmd = [self._python, "-u", "-m", image] + [str(a) for a in args]
         env = dict(os.environ)
         env.update(self._extra_env)
+        for kv in c.get("env") or []:
+            env[str(kv["name"])] = str(kv.get("value", ""))
         uid = t.name.split("-ps-")[0].split("-worker-")[0][3:]
         env["DTF_TASK_NAME"] = t.name
         env["DTF_DNS"] = json.dumps(self.dns_map(uid))

@@ -113,6 +113,11 @@ def gen_job(uid, work_type, seq, count, info, ps, workers, cfg=None):
     res = gen_resources(info.get("resource"), work_type, cfg)
     if res:
         container["resources"] = res
+    # job-level facts every task of the job must agree on (a ps task has no device of its own to look at):
+    # the placement is derived from these, never from the task's own GPU count
+    r = info.get("resource") or {}
+    container["env"] = [{"name": "DTF_JOB_WORKER_GPUS", "value": str(int(r.get("gpu", 0) or 0))},
+                        {"name": "DTF_JOB_PS_GPUS", "value": str(int(r.get("ps_gpu", 0) or 0))}]
     spec_extra = {}
     if info.get("timeout"):
         # job-level time limit (k8s activeDeadlineSeconds); the launcher fails the task when it expires

@@ -27,6 +27,8 @@ class TrainOptions:
     steps: int = 100
     batch: int = 64                 # per worker
     update_mode: str = "sync"       # sync | stale | async
+    staleness: int = 1              # stale mode: updates become visible this many steps late
+    ps_shards: str = "spec"         # spec: detail.ps shard groups (ps >= workers: one per worker) | auto: one per worker
     placement: str = "auto"         # auto | colocated | dedicated
     bucket_mb: float = 32.0
     wire_dtype: str = "auto"        # auto | bf16 | fp32
@@ -38,11 +40,11 @@ class TrainOptions:
     seed: int = 1234
     log_every: int = 10
     fault: str = ""                 # e.g. "exit:worker=1,step=3,code=17" / "hang:worker=0,step=2"
-    graph: bool = False
+    graph: bool = False             # capture the whole training step in one hipGraph after 3 eager steps
     extra: dict = field(default_factory=dict)
 
 
-_INT = {"steps", "batch", "ckpt_every", "seed", "log_every"}
+_INT = {"steps", "batch", "ckpt_every", "seed", "log_every", "staleness"}
 _FLOAT = {"bucket_mb", "lr"}
 _BOOL = {"resume", "graph"}
 
@@ -62,7 +64,7 @@ def parse_file_field(file_field, cfg=None):
     ``ValueError`` for something that is neither."""
     cfg = cfg or ApiConfig()
     opts = TrainOptions()
-    for key in ("steps", "bucket_mb", "update_mode", "placement", "wire_dtype"):
+    for key in ("steps", "bucket_mb", "update_mode", "placement", "wire_dtype", "staleness", "ps_shards", "graph"):
         if cfg.has_option("train", key):
             setattr(opts, key, _coerce(key, cfg.get("train", key)))
     f = (file_field or "").strip()

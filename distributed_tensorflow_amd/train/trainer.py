@@ -79,11 +79,11 @@ def _embedding_modules(model):
     return [(n, m) for n, m in model.named_modules() if isinstance(m, ShardedEmbedding)]
 
 
-def replicated_state(model, ps):
+def replicated_state(model, ps, step=None):
     """Non-PS state saved by the chief: global_step and BatchNorm moving statistics (sharded
     embedding tables are NOT replicated state: every rank writes its own part)."""
     skip = tuple(n + "." for n, _ in _embedding_modules(model))
-    rep = {"global_step": torch.tensor(ps.global_step, dtype=torch.int64)}
+    rep = {"global_step": torch.tensor(ps.global_step if step is None else step, dtype=torch.int64)}
     for n, b in model.named_buffers():
         if not n.startswith(skip) if skip else True:
             rep[n] = b
@@ -115,17 +115,43 @@ def restore_checkpoint(model, ps, export, tf_names):
 
 
 def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=None, on_step=None,
-               items_per_step=None, start_step=0):
-    """Runs ``steps`` PS steps; returns (last_loss, seconds, steps_done)."""
+               items_per_step=None, start_step=0, graph=False):
+    """Runs ``steps`` PS steps; returns (last_loss, seconds, steps_done).  ``graph=True``: after three eager steps
+    the whole step (forward, backward, hook-launched PS pipeline incl. its collectives) is captured in one hipGraph
+    and replayed -- the ~600 launches of a step then cost the host one call (GPU only)."""
     dev = ps.device
     t0 = time.time()
     last = None
     loss = None
+
+    def eager():
+        out = mod.loss_fn(model, batch)
+        out.backward()
+        ps.step()
+        return out
+
+    replay, static_loss = None, None
     for it in range(start_step, start_step + steps):
         _inject(fault, worker, it + 1)
-        loss = mod.loss_fn(model, batch)
-        loss.backward()
-        ps.step()
+        if graph and dev.type == "cuda" and replay is None and it - start_step == 3:
+            torch.cuda.synchronize(dev)
+            time.sleep(0.5)             # the RCCL watchdog retires the earlier collectives (no event queries mid-capture)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    static_loss = eager()
+                replay = g
+                ps.global_step -= 1     # the capture ran no kernels; the replay below is this step
+                print("[train] step captured in a hipGraph", flush=True)
+            except Exception as e:      # noqa: BLE001 -- stay eager rather than fail the job
+                print("[train] hipGraph capture failed (%s); staying eager" % type(e).__name__, flush=True)
+                graph = False
+        if replay is not None:
+            replay.replay()
+            ps.global_step += 1
+            loss = static_loss
+        else:
+            loss = eager()
         if on_step is not None:
             on_step(it + 1, loss)
         if log_every and (it + 1) % log_every == 0:
@@ -149,7 +175,10 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     use_cuda = torch.cuda.is_available() and int(os.environ.get("DTF_NUM_GPUS", "1")) > 0
     device = torch.device("cuda", 0) if use_cuda else torch.device("cpu")
     torch.manual_seed(opts.seed)
-    comm = Comm.from_env(device)
+    # the colocated asynchronous mode uses NO collective in the step (one-sided applies over peer-mapped shards):
+    # its process group is control-plane only, and gloo lets several ranks share a GPU
+    one_sided = placement != "dedicated" and opts.update_mode == "async"
+    comm = Comm.from_env(device, backend="gloo" if one_sided else None)
     chief = job_name == "worker" and task_index == 0
     if chief:
         metrics(t_comm_ready=time.time())
@@ -171,7 +200,9 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
                        "async" if opts.update_mode in ("async", "stale") else "sync")
         print("[ps %d] serving shard of %d elements (%s)" % (task_index, srv.layout.shard_total,
                                                              srv.update_mode), flush=True)
-        steps = srv.serve()
+        from ..parallel.dedicated_ps import agree_on_step
+
+        steps = agree_on_step(comm, srv.serve())
         print("[ps %d] all workers done after %d applies" % (task_index, steps), flush=True)
         if do_ckpt:
             sec = {"": srv.master}
@@ -180,8 +211,11 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
                 sec[names[0]] = srv.slot_m
             if len(names) > 1:
                 sec[names[1]] = srv.slot_v
-            ckpt.write_shard(export, opts.steps, task_index, num_ps, sec)
+            ckpt.write_shard(export, steps, task_index, num_ps, sec)
             print("[ps %d] wrote checkpoint shard" % task_index, flush=True)
+        # shards first, index second: the chief publishes the index + 'checkpoint' pointer only after every PS task
+        # has passed this barrier, so a reader that follows the pointer always finds the data files
+        comm.barrier()
         return 0
 
     # ------------------------------------------------------------ worker task
@@ -193,9 +227,19 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
         ps = PSWorkerClient(named, comm, num_ps, opt, opts.bucket_mb, wire,
                             "async" if opts.update_mode in ("async", "stale") else "sync")
         ps.device = device
+    elif one_sided:
+        from ..parallel.async_ps import AsyncPS
+
+        ps = AsyncPS(named, comm, opt, opts.bucket_mb, wire)
     else:
-        ps = ShardedPS(named, comm, opt, opts.bucket_mb, wire,
-                       "stale" if opts.update_mode in ("async", "stale") else "sync", opts.push)
+        # detail.ps = number of shard groups hosting the variables (the reference creates that many PS tasks,
+        # handlers/train_handler.py:96-112); P >= W (or ps_shards=auto) spreads them over every worker rank
+        shards = num_ps if (opts.ps_shards == "spec" and num_ps >= 1) else None
+        ps = ShardedPS(named, comm, opt, opts.bucket_mb, wire, "stale" if opts.update_mode == "stale" else "sync",
+                       opts.push, num_shards=shards, staleness=opts.staleness)
+    print("[worker %d] PS runtime: %s, update_mode=%s, shard groups=%d, push=%s" % (
+        task_index, type(ps).__name__, ps.update_mode, getattr(ps, "num_shards", num_ps), getattr(ps, "push", "-")),
+        flush=True)
     tf_names = mod.tf_variable_names(model) if hasattr(mod, "tf_variable_names") else {}
     start_step = 0
     if opts.resume and do_ckpt and placement != "dedicated" and ckpt.latest_step(export) is not None:
@@ -223,18 +267,28 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     remaining = max(0, opts.steps - start_step)
     items = opts.batch * num_workers
     last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
-                               fault=fault, on_step=on_step, items_per_step=items, start_step=start_step)
+                               fault=fault, on_step=on_step, items_per_step=items, start_step=start_step,
+                               graph=opts.graph and placement != "dedicated" and not one_sided)
     rate = n * items / max(secs, 1e-9)
     print("[worker %d] done: %d steps in %.2f s, %.1f items/s, final loss %s" % (
         task_index, n, secs, rate, last), flush=True)
     if placement == "dedicated":
-        ps.finish()
+        applies = ps.finish()
+        comm.barrier()          # every PS task has written its shard (see the ps branch above)
         if do_ckpt and chief:
             shapes = {nm: tuple(p.shape) for nm, p in ps.named_params}
-            variables = ckpt.dense_variable_index(ps.layout, tf_names, shapes, opt.slots)
-            ckpt.write_index(export, opts.steps, num_ps, variables, extra={"optimizer": opt.kind})
-    elif do_ckpt:
-        save_checkpoint(model, ps, export, ps.global_step, tf_names, chief)
+            orders = {nm: ckpt.storage_order(p) for nm, p in ps.named_params}
+            variables = ckpt.dense_variable_index(ps.layout, tf_names, shapes, opt.slots, orders)
+            ckpt.write_replicated(export, applies, replicated_state(model, ps, applies))
+            ckpt.write_index(export, applies, num_ps, variables, extra={"optimizer": opt.kind,
+                                                                         "placement": "dedicated"})
+    else:
+        if one_sided:
+            ps.finish()         # every worker's last apply has landed
+        if do_ckpt:
+            save_checkpoint(model, ps, export, ps.global_step, tf_names, chief)
+        if one_sided:
+            ps.close()
     if chief:
         metrics(t_done=time.time(), step=ps.global_step, items_per_sec=rate,
                 final_loss=last if last is not None else "nan")

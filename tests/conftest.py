@@ -42,3 +42,17 @@ def _clean_config():
 
     yield
     ApiConfig.clear_overrides()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _close_process_group():
+    """GPU tests keep one live 1-rank RCCL group for the session; close it explicitly (an open group at exit is a
+    warning today and a hang source with more ranks)."""
+    yield
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass

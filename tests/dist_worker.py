@@ -122,10 +122,72 @@ def real_layout_case(comm, out_dir, case):
     comm.close()
 
 
+def async_case(comm, out_dir, case, device=None):
+    """One-sided asynchronous PS (parallel/async_ps.py).  ``asyncserial``: the workers take turns (a barrier per
+    turn), so the result must equal applying their gradients one after the other -- exact.  ``asyncfree``: no
+    synchronisation at all, worker 1 sleeps between steps: worker 0 must NOT be slowed down by it (its step count
+    races ahead), every apply is counted by the owners, and the loss still falls."""
+    import time
+
+    import torch.distributed as dist
+
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncPS
+
+    r, W = comm.rank, comm.world_size
+    device = device or torch.device("cpu")
+    torch.manual_seed(7)
+    model = mnist_mlp.build().to(device)
+    kind = "adam" if "adam" in case else ("sgd" if "sgd" in case else "momentum")
+    opt = OptimizerSpec(kind=kind, lr=0.002 if kind == "adam" else 0.05, momentum=0.9)
+    ps = AsyncPS(list(model.named_parameters()), comm, opt, bucket_mb=0.02, wire_dtype=torch.float32)
+    x, y = mnist_mlp.synthetic_batch(64, seed=11)
+    per = 64 // W
+    batch = (x[r * per:(r + 1) * per].to(device), y[r * per:(r + 1) * per].to(device))
+    losses, steps_done = [], 0
+    if "serial" in case:
+        for it in range(3):
+            for turn in range(W):
+                if turn == r:
+                    ps.pull()
+                    loss = mnist_mlp.loss_fn(model, batch)
+                    loss.backward()
+                    ps.step()
+                    ps.flush()
+                    losses.append(float(loss.detach()))
+                    steps_done += 1
+                dist.barrier()
+    else:
+        t_end = time.time() + 1.5
+        while time.time() < t_end:
+            loss = mnist_mlp.loss_fn(model, batch)
+            loss.backward()
+            ps.step()
+            losses.append(float(loss.detach()))
+            steps_done += 1
+            if r == 1:
+                time.sleep(0.05)        # a slow worker
+    ps.finish()
+    counts = torch.tensor([float(steps_done)])
+    all_counts = [torch.zeros(1) for _ in range(W)]
+    dist.all_gather(all_counts, counts)
+    applies = ps.applies_received()
+    full = ps.full_master().cpu()
+    if r == 0:
+        params = {n: ps.param_from_flat(full, i).clone() for i, (n, _) in enumerate(ps.named_params)}
+        torch.save({"params": params, "losses": losses, "steps": [int(c) for c in all_counts], "applies": applies,
+                    "buckets": len(ps.layout.buckets)}, os.path.join(out_dir, "result_%s_w%d.pt" % (case, W)))
+    comm.barrier()
+    ps.close()
+    comm.close()
+
+
 def main():
     case, out_dir = sys.argv[1], sys.argv[2]
     comm = Comm.from_env(torch.device("cpu"), backend="gloo")
     r, W = comm.rank, comm.world_size
+    if case.startswith("async"):
+        dev = torch.device("cuda", 0) if case.endswith("_gpu") else None
+        return async_case(comm, out_dir, case, dev)
     if case.startswith("widedeep"):
         return widedeep_case(comm, out_dir, case)
     if case.startswith("real_"):

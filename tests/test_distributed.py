@@ -125,6 +125,45 @@ def test_real_layouts_bf16_wire_replicas_stay_in_sync(tmp_path, case, world):
     assert all(l == l and l < 1e4 for l in res["losses"])
 
 
+def _sequential_reference(world, kind):
+    """Workers take turns on ONE copy of the variables: w0 step, w1 step, ... (what asyncserial must equal)."""
+    from distributed_tensorflow_amd.models import mnist_mlp
+
+    torch.manual_seed(7)
+    model = mnist_mlp.build()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9 if kind == "momentum" else 0.0)
+    x, y = mnist_mlp.synthetic_batch(64, seed=11)
+    per = 64 // world
+    for _ in range(3):
+        for r in range(world):
+            opt.zero_grad()
+            mnist_mlp.loss_fn(model, (x[r * per:(r + 1) * per], y[r * per:(r + 1) * per])).backward()
+            opt.step()
+    return {n: p.detach().clone() for n, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("case,world", [("asyncserial_momentum", 2), ("asyncserial_sgd", 4)])
+def test_one_sided_async_ps_serialised_equals_sequential_sgd(tmp_path, case, world):
+    """The one-sided asynchronous PS with the workers taking turns == plain sequential SGD on one copy of the
+    variables: every worker's apply lands on the owners' shards un-averaged, and a pull sees all of them."""
+    res = run_ranks(world, case, tmp_path)
+    ref = _sequential_reference(world, "momentum" if "momentum" in case else "sgd")
+    assert res["buckets"] >= 2 and res["applies"] == 3 * world
+    for n, p in ref.items():
+        torch.testing.assert_close(res["params"][n], p, rtol=1e-5, atol=1e-6, msg=lambda m: "%s: %s" % (n, m))
+
+
+def test_one_sided_async_ps_workers_do_not_wait_for_each_other(tmp_path):
+    """Free-running: worker 1 sleeps 50 ms per step, worker 0 must not be held back by it (TF1 async semantics: no
+    barrier anywhere in the step), the owners count every apply, and training converges."""
+    res = run_ranks(2, "asyncfree_momentum", tmp_path)
+    fast, slow = res["steps"]
+    assert slow <= 31 and fast > 2 * slow, res["steps"]
+    # rank 0's shard saw its own applies + worker 1's (a racy counter: allow a few lost increments)
+    assert fast + slow - 5 <= res["applies"] <= fast + slow
+    assert res["losses"][-1] < 0.5 * res["losses"][0]
+
+
 def test_checkpoint_resharding_2_to_4_ranks(tmp_path):
     """Save at step 3 on 2 ranks, resume on 4 ranks, finish: equals uninterrupted training."""
     full = run_ranks(2, "save_momentum", tmp_path)

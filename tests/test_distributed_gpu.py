@@ -1,0 +1,245 @@
+"""The multi-GPU code paths on ONE MI355X: a live 1-rank RCCL group makes every collective of the PS data plane
+really run (reduce_scatter / all_to_all / all_gather / all_reduce on the comm stream, launched from the autograd
+hooks, bf16 wire, in-place slices), and the result must be bitwise what the collective-free path leaves.  Plus the
+numerics of the device-side embedding router against its framework-op reference."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from distributed_tensorflow_amd.ops import hip
+
+    hip.lib()
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def rccl(dev):
+    import torch.distributed as dist
+
+    from distributed_tensorflow_amd.parallel.comm import Comm
+
+    comm = Comm.from_env(dev, backend="nccl", force=True)
+    assert comm.live and dist.get_backend() == "nccl"
+    yield comm
+    comm.barrier()
+
+
+@pytest.mark.parametrize("push", ["reduce_scatter", "all_to_all"])
+def test_bert_clipped_adam_through_rccl_single_rank(dev, rccl, push):
+    """BERT's optimizer clips by global norm: packs + pushes run from the hooks, sum-of-squares (with the all-to-all
+    slab sum fused in), the scalar all-reduce, K2 apply and the all-gather after backward.  Bitwise == no-comm path."""
+    from distributed_tensorflow_amd.models import bert
+    from distributed_tensorflow_amd.parallel.comm import Comm
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+
+    torch.manual_seed(0)
+    m1 = bert.prepare(bert.build(layers=2, hidden=256, heads=4, intermediate=1024, vocab=3000), dev)
+    m2 = copy.deepcopy(m1)
+    batch = bert.synthetic_batch(4, device=dev, seed=1, seq_len=128, vocab=3000)
+    opt = bert.default_optimizer()
+    ps1 = ShardedPS(list(m1.named_parameters()), rccl, opt, bucket_mb=1, push=push)
+    ps2 = ShardedPS(list(m2.named_parameters()), Comm.single(dev), opt, bucket_mb=1)
+    assert ps1.gnorm_sq is not None and len(ps1.layout.buckets) > 3
+    assert sorted({b.group for b in ps1.layout.buckets}) == [0, 1]        # decayed / not decayed
+    for _ in range(3):
+        bert.loss_fn(m1, batch).backward()
+        assert any(ps1._launched), "hooks must have pushed buckets during backward"
+        for p, q in zip(m1.parameters(), m2.parameters()):
+            q.grad = p.grad.clone()
+        ps1.step()
+        ps2.step()
+        torch.cuda.synchronize()
+        assert torch.equal(ps1.gnorm_sq, ps2.gnorm_sq)
+        assert torch.equal(ps1.master, ps2.master)
+        assert torch.equal(ps1.slot_v, ps2.slot_v)
+        assert torch.equal(ps1.param_flat, ps2.param_flat)
+    ps1.remove_hooks()
+    ps2.remove_hooks()
+
+
+def test_stale2_through_rccl_single_rank(dev, rccl):
+    from distributed_tensorflow_amd.models import resnet
+    from distributed_tensorflow_amd.parallel.comm import Comm
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+
+    torch.manual_seed(0)
+    m1 = resnet.prepare(resnet.build(), dev)
+    m2 = copy.deepcopy(m1)
+    batch = resnet.synthetic_batch(4, device=dev, seed=1, image_size=64)
+    ps1 = ShardedPS(list(m1.named_parameters()), rccl, resnet.default_optimizer(), update_mode="stale", staleness=2)
+    ps2 = ShardedPS(list(m2.named_parameters()), Comm.single(dev), resnet.default_optimizer(), update_mode="stale",
+                    staleness=2)
+    init = ps1.param_flat.clone()
+    for it in range(4):
+        resnet.loss_fn(m1, batch).backward()
+        for p, q in zip(m1.parameters(), m2.parameters()):
+            q.grad = p.grad.clone()
+        ps1.step()
+        ps2.step()
+        torch.cuda.synchronize()
+        if it < 2:
+            assert torch.equal(ps1.param_flat, init), "updates must stay invisible for two steps"
+        assert torch.equal(ps1.param_flat, ps2.param_flat)
+    assert not torch.equal(ps1.param_flat, init)
+    ps1.flush()
+    ps2.flush()
+    assert torch.equal(ps1.param_flat, ps2.param_flat) and torch.equal(ps1.master, ps2.master)
+
+
+@pytest.mark.parametrize("partition", ["mod", "div"])
+def test_wide_deep_routing_through_rccl_single_rank(dev, rccl, partition):
+    """ShardedEmbedding honours a live 1-rank group: route kernel + three all-to-alls through RCCL, rows back through
+    the slots, gradients to the owner -- tables and accumulators bitwise equal to the direct gather / apply."""
+    from distributed_tensorflow_amd.models import wide_deep as wd
+    from distributed_tensorflow_amd.parallel.comm import Comm
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+
+    kw = dict(num_features=6, rows_per_table=5000, embedding_dim=16)
+    torch.manual_seed(0)
+    m1 = wd.prepare(wd.build(comm=rccl, device=dev, partition=partition, **kw), dev)
+    torch.manual_seed(0)
+    m2 = wd.prepare(wd.build(comm=Comm.single(dev), device=dev, **kw), dev)
+    m2.embeddings.table.copy_(m1.embeddings.table)
+    ps1 = ShardedPS(list(m1.named_parameters()), rccl, wd.default_optimizer())
+    ps2 = ShardedPS(list(m2.named_parameters()), Comm.single(dev), wd.default_optimizer())
+    batch = wd.synthetic_batch(4096, device=dev, seed=3, model=m1)
+    for _ in range(3):
+        l1 = wd.loss_fn(m1, batch)
+        l1.backward()
+        ps1.step()
+        l2 = wd.loss_fn(m2, batch)
+        l2.backward()
+        ps2.step()
+        torch.cuda.synchronize()
+        assert torch.equal(l1, l2)
+        assert torch.equal(m1.embeddings.table, m2.embeddings.table)
+        assert torch.equal(m1.embeddings.accumulator, m2.embeddings.accumulator)
+    assert m1.embeddings.check_overflow() == 0 and m1.embeddings._lookups == 3
+
+
+@pytest.mark.parametrize("n,W,cap,div", [(1, 1, 1, False), (1000, 2, 600, False), (5000, 8, 700, False),
+                                         (5000, 8, 500, False), (4097, 3, 2000, True), (70000, 8, 9000, True),
+                                         (300000, 16, 20000, False), (1024, 4, 256, False)])
+def test_route_kernel_matches_reference(dev, n, W, cap, div):
+    """Stable bucket-by-owner split: slot of request i = owner * cap + (number of earlier requests of that owner);
+    requests beyond the capacity are dropped and counted; padding ids (negative / out of range) get slot -1."""
+    from distributed_tensorflow_amd.ops import embedding as E
+
+    g = torch.Generator().manual_seed(n + W)
+    total = 1000003
+    ids = (torch.rand(n, generator=g) ** 3 * total).long()
+    if n > 10:
+        ids[::97] = -1
+        ids[5] = total + 3
+    rows_per = (total + W - 1) // W
+    ref = E.route_reference(ids, W, cap, div, rows_per, total)
+    ovf = torch.zeros(1, dtype=torch.int64, device=dev)
+    got = E.embedding_route(ids.to(dev), W, cap, div, rows_per, total, ovf)
+    torch.cuda.synchronize()
+    for name, a, b in zip(("send_ids", "slot", "inv", "totals"), got, ref[:4]):
+        assert torch.equal(a.cpu(), b), name
+    assert int(ovf) == int(ref[4])
+    if cap * W < n:
+        assert int(ovf) > 0
+
+
+@pytest.mark.parametrize("nsrc", [1, 2, 8])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_sumsq_fused_slab_sum(dev, nsrc, dtype):
+    from distributed_tensorflow_amd.ops import reduce
+
+    n, stride = 100003, 100008
+    torch.manual_seed(nsrc)
+    x = torch.randn(nsrc * stride, device=dev).to(dtype)
+    out = torch.zeros(1, device=dev)
+    reduce.sumsq(x, out, n=n, nsrc=nsrc, src_stride=stride)
+    acc = sum(x[s * stride:s * stride + n].float() for s in range(nsrc))
+    ref = (acc.double() ** 2).sum()
+    assert abs(float(out) - float(ref)) <= 1e-5 * float(ref)
+    reduce.sumsq(x, out, accumulate=True, n=n, nsrc=nsrc, src_stride=stride)
+    assert abs(float(out) - 2 * float(ref)) <= 1e-5 * 2 * float(ref)
+
+
+@pytest.mark.parametrize("name", ["mnist_mlp", "bert"])
+def test_whole_step_hipgraph_with_live_rccl_is_bitwise_eager(dev, rccl, name):
+    """The whole step -- forward, backward, the hook-launched PS pipeline with its RCCL collectives on the comm
+    stream -- captured in ONE hipGraph and replayed must leave bitwise what the eager step leaves."""
+    import time
+
+    from distributed_tensorflow_amd.models import get_model_module
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+
+    mod = get_model_module(name)
+    torch.manual_seed(0)
+    kw = dict(layers=2, hidden=256, heads=4, intermediate=1024, vocab=3000) if name == "bert" else {}
+    m1 = mod.prepare(mod.build(**kw), dev) if hasattr(mod, "prepare") else mod.build(**kw).to(dev)
+    m2 = copy.deepcopy(m1)
+    bkw = dict(seq_len=128, vocab=3000) if name == "bert" else {}
+    batch = mod.synthetic_batch(8, device=dev, seed=1, **bkw)
+    opt = mod.default_optimizer()
+    ps1 = ShardedPS(list(m1.named_parameters()), rccl, opt, bucket_mb=0.05)
+    ps2 = ShardedPS(list(m2.named_parameters()), rccl, opt, bucket_mb=0.05)
+    assert len(ps1.layout.buckets) >= 2
+
+    def step(m, ps):
+        loss = mod.loss_fn(m, batch)
+        loss.backward()
+        ps.step()
+        return loss
+
+    # both models take 3 eager steps (graph capture needs warm kernels / allocator / RCCL channels)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step(m1, ps1)
+            step(m2, ps2)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert torch.equal(ps1.param_flat, ps2.param_flat)
+    time.sleep(0.5)                       # let the RCCL watchdog retire the warm-up collectives
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        static_loss = step(m2, ps2)       # capture runs nothing: m2 is one step behind until the first replay
+    losses = []
+    for _ in range(4):
+        l1 = step(m1, ps1)
+        g.replay()
+        torch.cuda.synchronize()
+        losses.append(float(l1))
+        assert torch.equal(l1, static_loss)
+        assert torch.equal(ps1.master, ps2.master)
+        assert torch.equal(ps1.param_flat, ps2.param_flat)
+    assert losses[-1] < losses[0]
+    ps1.remove_hooks()
+    ps2.remove_hooks()
+
+
+def test_one_sided_async_ps_two_workers_share_one_gpu(dev, tmp_path):
+    """The asynchronous PS on device memory: two worker PROCESSES on this one GPU (RCCL would refuse that; the mode
+    needs no collective), each hosting one shard in hipMalloc memory that the other maps through HIP IPC and
+    updates with the K1 kernel.  Workers take turns here, so the result must equal sequential SGD exactly."""
+    from test_distributed import _sequential_reference, run_ranks
+
+    res = run_ranks(2, "asyncserial_momentum_gpu", tmp_path, timeout=240)
+    ref = _sequential_reference(2, "momentum")
+    assert res["applies"] == 6
+    for n, p in ref.items():
+        torch.testing.assert_close(res["params"][n], p, rtol=1e-5, atol=1e-6, msg=lambda m: "%s: %s" % (n, m))
+
+
+def test_one_sided_async_ps_free_running_on_gpu(dev, tmp_path):
+    from test_distributed import run_ranks
+
+    res = run_ranks(2, "asyncfree_momentum_gpu", tmp_path, timeout=240)
+    fast, slow = res["steps"]
+    assert fast > 2 * slow, res["steps"]
+    assert res["losses"][-1] < 0.5 * res["losses"][0]
