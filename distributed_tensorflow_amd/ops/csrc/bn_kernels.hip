@@ -119,6 +119,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
     float s1[8], s2[8], mu[8], sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; sc[k] = 0.f; sh[k] = 0.f; }
+    if (MODE == BN_FWD_STATS && cvalid) {
+        // shifted accumulation: sums of (x - s) and (x - s)^2 with s = the channel's value in row 0 (a sample of
+        // the distribution, identical for every block).  var = E[d^2] - E[d]^2 then cancels only digits of the
+        // SPREAD, not of the mean: E[x^2] - E[x]^2 in fp32 loses the variance once |mean| > ~300 std.
+        ld8bf(x + c0, mu);
+    }
     if (MODE != BN_FWD_STATS && cvalid) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) mu[k] = mean[c0 + k];
@@ -152,8 +158,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (MODE == BN_FWD_STATS) {
-                        s1[k] += xv[u][k];
-                        s2[k] = fmaf(xv[u][k], xv[u][k], s2[k]);
+                        const float d = xv[u][k] - mu[k];
+                        s1[k] += d;
+                        s2[k] = fmaf(d, d, s2[k]);
                     } else {
                         float d = dv[u][k];
                         if (MODE == BN_BWD_RELU_X) d = fmaf(xv[u][k], sc[k], sh[k]) > 0.f ? d : 0.f;
@@ -243,14 +250,18 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
                                                               const void* beta, float* running_mean,
                                                               float* running_var, float momentum, float eps,
                                                               float* mean_out, float* invstd_out,
-                                                              float* scale_out, float* shift_out) {
+                                                              float* scale_out, float* shift_out,
+                                                              const unsigned short* __restrict__ x0) {
+    // x0: row 0 of the tensor the partials were accumulated against (bn_reduce_kernel's shift), or null when the
+    // partials are plain sums (K6 STATS epilogue)
     const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
     float s1, s2;
     reduce_partials8(partial, nblk, C, s1, s2);
     if (threadIdx.x < BN_FIN_CH && c < C) {
-        const double m = (double)s1 * inv_count;
-        double var = (double)s2 * inv_count - m * m;
+        const double md = (double)s1 * inv_count;
+        double var = (double)s2 * inv_count - md * md;
         if (var < 0.0) var = 0.0;
+        const double m = md + (x0 ? (double)bf16_to_f32(x0[c]) : 0.0);
         const float mean = (float)m;
         const float invstd = rsqrtf((float)var + eps);
         const float g = load1<PDT>(gamma, c), b = load1<PDT>(beta, c);
@@ -684,11 +695,11 @@ int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const 
     if (param_dtype == DTF_BF16)
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
                            inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
-                           scale, shift);
+                           scale, shift, (const unsigned short*)x);
     else
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
                            inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
-                           scale, shift);
+                           scale, shift, (const unsigned short*)x);
     launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, ldy, ldx, stream);
     DTF_CHECK_LAUNCH();
     return 0;
@@ -709,10 +720,12 @@ int dtf_bn_stats_train(const void* x, const void* gamma, const void* beta, int p
     const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
     if (param_dtype == DTF_BF16)
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C, inv_count,
-                           unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                           unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                           (const unsigned short*)x);
     else
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C, inv_count,
-                           unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                           unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                           (const unsigned short*)x);
     DTF_CHECK_LAUNCH();
     return 0;
 }
@@ -734,11 +747,11 @@ int dtf_bn_fwd_train_pre(const void* x, const void* res, void* y, void* mask, co
     if (param_dtype == DTF_BF16)
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C,
                            inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
-                           scale, shift);
+                           scale, shift, (const unsigned short*)nullptr);
     else
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C,
                            inv_count, unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
-                           scale, shift);
+                           scale, shift, (const unsigned short*)nullptr);
     launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, ldy, (int64_t)C, stream);
     DTF_CHECK_LAUNCH();
     return 0;
@@ -852,10 +865,10 @@ int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const
     do {                                                                                                                      \
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pa, nb, C, inv_count, unbias,    \
                            gamma_a, beta_a, rm_a, rv_a, momentum_a, eps_a, stats_a, stats_a + C, stats_a + 2 * C,             \
-                           stats_a + 3 * C);                                                                                  \
+                           stats_a + 3 * C, xas);                                                                             \
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pb, nb, C, inv_count, unbias,    \
                            gamma_b, beta_b, rm_b, rv_b, momentum_b, eps_b, stats_b, stats_b + C, stats_b + 2 * C,             \
-                           stats_b + 3 * C);                                                                                  \
+                           stats_b + 3 * C, xbs);                                                                             \
     } while (0)
     if (param_dtype == DTF_BF16) FIN(DTF_BF16); else FIN(DTF_F32);
 #undef FIN

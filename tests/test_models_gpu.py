@@ -1,0 +1,253 @@
+"""Whole-model correctness on the GPU: the shipped fused graphs -- dual-BatchNorm node,
+BatchNorm inside the stem pool, gradient forks, data gradients as forward convolutions, 1x1 convolutions as GEMMs,
+K6T weight gradients, fused Inception heads, all together -- against a plain fp32 model built from the same weights,
+on loss AND every parameter gradient; a convergence smoke with learning-rate warm-up; BatchNorm statistics when
+|mean| >> std.
+
+What "agrees with fp32" can mean for a 50-layer ReLU network (measured, fp32 on the CPU, stock modules): at the default
+init the parameter gradients are a DISCONTINUOUS function of the activations -- an input perturbation of 1e-4 moves
+every gradient by ~25 %, fp32 vs fp64 alone differ by 1.5 % (relative error ~ sqrt(fraction of ReLU / max-pool
+decisions that flip)).  bf16-vs-fp32 at that init therefore measures chaos, not wiring, for ANY implementation:
+the stock modules run in bf16 are as far from fp32 (relative error ~1.2) as the fused graph is.  Two regimes are
+tested instead:
+  * linearised: BatchNorm betas = +3 (pre-activations 3 sigma above zero, almost no decision flips): gradients are
+    smooth, and the fused bf16 graph must track fp32 as closely as stock bf16 modules do, parameter by parameter --
+    a mis-wired fork / dual-BN / fused-pool / dgrad path is an O(1) error on the parameters behind it;
+  * default init: the error LEVEL must match the stock-bf16 control's.
+"""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from distributed_tensorflow_amd.ops import hip
+
+    hip.lib()
+    return torch.device("cuda", 0)
+
+
+# --------------------------------------------------------------------------- stock reference
+class _StockBottleneck(nn.Module):
+    """ResNet v1.5 bottleneck out of stock modules only; attribute names = the shipped model's, so its state_dict loads."""
+
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        out = planes * 4
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, out, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(out)
+        self.shortcut_conv = self.shortcut_bn = None
+        if stride != 1 or inplanes != out:
+            self.shortcut_conv = nn.Conv2d(inplanes, out, 1, stride=stride, bias=False)
+            self.shortcut_bn = nn.BatchNorm2d(out)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        sc = x if self.shortcut_conv is None else self.shortcut_bn(self.shortcut_conv(x))
+        return F.relu(y + sc)
+
+
+class _StockResNet50(nn.Module):
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        blocks, inplanes = [], 64
+        for stage, n in enumerate((3, 4, 6, 3)):
+            planes = 64 << stage
+            units = []
+            for u in range(n):
+                units.append(_StockBottleneck(inplanes, planes, 2 if (u == 0 and stage > 0) else 1))
+                inplanes = planes * 4
+            blocks.append(nn.Sequential(*units))
+        self.block1, self.block2, self.block3, self.block4 = blocks
+        self.fc = nn.Linear(inplanes, num_classes)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
+        x = self.block4(self.block3(self.block2(self.block1(x))))
+        return self.fc(x.mean((2, 3)))
+
+
+def _rel_fro(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _grad_errors(named, named_ref):
+    """Relative Frobenius error per parameter.  Parameters whose TRUE gradient is (numerically) zero -- a BatchNorm
+    beta in front of conv + BatchNorm when the ReLU between them is linear: the next BatchNorm removes any constant --
+    are measured against the typical gradient norm instead of their own."""
+    norms = sorted(float(q.grad.double().norm()) for _, q in named_ref)
+    floor = 1e-2 * norms[len(norms) // 2]
+    errs = {}
+    for (n, p), (_, q) in zip(named, named_ref):
+        assert p.grad is not None and q.grad is not None, n
+        a, b = p.grad.detach().double().cpu().reshape(-1), q.grad.double().reshape(-1)
+        errs[n] = float((a - b).norm() / max(float(b.norm()), floor))
+    return errs
+
+
+def _linearise(model, beta=3.0):
+    with torch.no_grad():
+        for m in model.modules():
+            if type(m).__name__ in ("FusedBatchNormAct", "BatchNorm2d"):
+                m.bias.fill_(beta)
+
+
+def _compare(name, named_ours, named_ref, loss_ours, loss_ref, loss_rel_tol, control=None, median_tol=0.15,
+             worst_tol=1.0):
+    """Loss within ``loss_rel_tol`` (relative) of the fp32 reference.  Gradients: where a precision-matched CONTROL
+    exists (the stock modules run in bf16 on the GPU: the error ANY bf16 implementation of this network has against
+    fp32), every parameter within 2x the control's own error (+0.03) and the median within 1.2x; without a control,
+    median below ``median_tol`` and nothing beyond ``worst_tol``.  Prints the distributions."""
+    errs = _grad_errors(named_ours, named_ref)
+    dl = abs(float(loss_ours) - float(loss_ref)) / abs(float(loss_ref))
+    vals = sorted(errs.values())
+    med, worst = vals[len(vals) // 2], vals[-1]
+    top = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    line = "%s: loss %.5f vs fp32 %.5f (rel %.5f); grad rel-Frobenius median %.4f, p90 %.4f, worst %.4f %s" % (
+        name, float(loss_ours), float(loss_ref), dl, med, vals[int(0.9 * len(vals))], worst,
+        [(n, round(e, 3)) for n, e in top])
+    if control is not None:
+        c_errs, c_loss = control
+        cv = sorted(c_errs.values())
+        line += " || stock-bf16 control: loss rel %.5f, median %.4f, p90 %.4f, worst %.4f" % (
+            abs(c_loss - float(loss_ref)) / abs(float(loss_ref)), cv[len(cv) // 2], cv[int(0.9 * len(cv))], cv[-1])
+    print(line)
+    loss_bound = loss_rel_tol if control is None else \
+        max(loss_rel_tol, 2.5 * abs(control[1] - float(loss_ref)) / abs(float(loss_ref)))
+    assert dl < loss_bound, line
+    if control is None:
+        assert med < median_tol and worst < worst_tol, line
+        return med, worst
+    cmed = sorted(control[0].values())[len(errs) // 2]
+    assert med <= 1.2 * cmed + 0.01, line
+    bad = {n: (round(e, 4), round(control[0][n], 4)) for n, e in errs.items() if e > 2.0 * control[0][n] + 0.03}
+    assert not bad, (line, bad)
+    return med, worst
+
+
+@pytest.mark.parametrize("linear", [True, False])
+def test_resnet50_fused_graph_matches_stock_fp32_model(dev, linear):
+    from distributed_tensorflow_amd.models import resnet
+
+    torch.manual_seed(0)
+    base = resnet.build()
+    if linear:
+        _linearise(base)
+    ours = resnet.prepare(base, dev)
+    ours.train()
+    ref = _StockResNet50()
+    missing = ref.load_state_dict({k: v.detach().float().cpu().contiguous() for k, v in ours.state_dict().items()},
+                                  strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("num_batches_tracked") for k in missing.missing_keys)
+    ref.train()
+    x, y = resnet.synthetic_batch(16, device=dev, seed=3, image_size=96)
+    loss = resnet.loss_fn(ours, (x, y))
+    loss.backward()
+    torch.cuda.synchronize()
+    # the reference sees exactly the bf16-rounded inputs, in fp32 on the CPU
+    xr = x.float().cpu().contiguous()
+    loss_ref = F.cross_entropy(ref(xr), y.cpu())
+    loss_ref.backward()
+    # precision-matched control: the SAME stock modules in bf16 NHWC on the GPU (framework kernels only)
+    ctl = copy.deepcopy(ref).to(device=dev, dtype=torch.bfloat16, memory_format=torch.channels_last)
+    ctl.zero_grad()
+    loss_ctl = F.cross_entropy(ctl(x).float(), y)
+    loss_ctl.backward()
+    torch.cuda.synchronize()
+    control = (_grad_errors(list(ctl.named_parameters()), list(ref.named_parameters())), float(loss_ctl))
+    _compare("resnet50 fused graph (%s)" % ("linearised" if linear else "default init"),
+             list(ours.named_parameters()), list(ref.named_parameters()), loss.detach(), loss_ref.detach(),
+             loss_rel_tol=2e-3, control=control)
+    # moving statistics updated like nn.BatchNorm2d
+    torch.testing.assert_close(ours.block2[0].shortcut_bn.running_mean.cpu(), ref.block2[0].shortcut_bn.running_mean,
+                               rtol=3e-2, atol=3e-3)
+    torch.testing.assert_close(ours.bn1.running_var.cpu(), ref.bn1.running_var, rtol=3e-2, atol=3e-3)
+
+
+def test_inception_v3_fused_graph_matches_fp32_reference_path(dev):
+    """No stock Inception ships in this image (no torchvision): the reference is the model's own fp32 CPU path, which
+    uses ``F.conv2d`` / ``F.batch_norm`` / ``F.max_pool2d`` / ``F.avg_pool2d`` per branch and none of the fusions.
+    Linearised regime; thresholds from the ResNet control's level at the same regime."""
+    from distributed_tensorflow_amd.models import inception_v3 as inc
+
+    torch.manual_seed(0)
+    ref = inc.build(aux_logits=True)
+    _linearise(ref)
+    ref.train()
+    ours = inc.prepare(copy.deepcopy(ref), dev)
+    ours.train()
+    x, y = inc.synthetic_batch(8, device=dev, seed=5)
+    loss = inc.loss_fn(ours, (x, y))
+    loss.backward()
+    torch.cuda.synchronize()
+    loss_ref = inc.loss_fn(ref, (x.float().cpu().contiguous(), y.cpu()))
+    loss_ref.backward()
+    _compare("inception_v3 fused graph (linearised)", list(ours.named_parameters()), list(ref.named_parameters()),
+             loss.detach(), loss_ref.detach(), loss_rel_tol=3e-3, median_tol=0.2, worst_tol=2.0)
+
+
+def test_resnet50_learns_with_warmup(dev):
+    """Convergence smoke: 40 steps on a fixed 32-image batch (64x64), lr warmed up 0.01 -> 0.05.  The loss must fall
+    well below ln(1000) and the second half must not blow up (r1's smoke went 6.9 -> 2.1 -> 14.2 at lr 0.1 cold)."""
+    from distributed_tensorflow_amd.models import resnet
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+
+    torch.manual_seed(0)
+    model = resnet.prepare(resnet.build(), dev)
+    model.train()
+    ps = ShardedPS(list(model.named_parameters()), opt=resnet.default_optimizer())
+    batch = resnet.synthetic_batch(32, device=dev, seed=1, image_size=64)
+    losses = []
+    for it in range(40):
+        ps.set_lr(0.01 + (0.05 - 0.01) * min(1.0, it / 10.0))
+        loss = resnet.loss_fn(model, batch)
+        loss.backward()
+        ps.step()
+        losses.append(float(loss.detach()))
+    print("resnet50 warm-up smoke losses:", [round(l, 3) for l in losses[::4]])
+    assert all(l == l for l in losses)
+    assert losses[-1] < 0.5 * losses[0], losses
+    assert max(losses[20:]) < losses[0] + 0.5, losses              # no blow-up once warmed up
+    assert sum(losses[-5:]) / 5 < sum(losses[:5]) / 5 - 2.0, losses
+
+
+@pytest.mark.parametrize("mean,std", [(0.5, 2.0), (200.0, 0.5), (-3000.0, 4.0)])
+def test_batchnorm_statistics_with_mean_far_from_zero(dev, mean, std):
+    """Variance as E[x^2] - E[x]^2 over 8e5 samples loses everything in fp32 once |mean| >> std; the kernels
+    accumulate around a per-channel shift instead.  Reference: fp64 on the same bf16 values."""
+    from distributed_tensorflow_amd.ops.batchnorm import fused_bn_act
+
+    torch.manual_seed(1)
+    N, C, H, W = 64, 64, 112, 112
+    x = (mean + std * torch.randn(N, C, H, W, device=dev)).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (1.0 + 0.1 * torch.randn(C, device=dev)).to(torch.bfloat16)
+    b = (0.1 * torch.randn(C, device=dev)).to(torch.bfloat16)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    y = fused_bn_act(x, w, b, None, rm, rv, True, 0.1, 1e-5, relu=False)
+    xd = x.double()
+    mu = xd.mean((0, 2, 3))
+    var = xd.var((0, 2, 3), unbiased=False)
+    ref = (xd - mu[None, :, None, None]) / torch.sqrt(var + 1e-5)[None, :, None, None] * w.double()[None, :, None, None] \
+        + b.double()[None, :, None, None]
+    err = (y.double() - ref).abs().max()
+    # the output is bf16: half an ulp at |y| <= 6 is 0.016
+    assert float(err) < 0.04, float(err)
+    torch.testing.assert_close(rm.double(), 0.1 * mu, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(rv.double(), 0.9 + 0.1 * var * (N * H * W) / (N * H * W - 1), rtol=2e-3, atol=1e-4)
