@@ -127,13 +127,19 @@ def build(comm=None, device=None, **kw):
 def prepare(model, device):
     device = torch.device(device)
     emb = model.embeddings
+    # the tables are sized for HBM (100+ GB): they were created on their device in their final dtype, so they are
+    # detached while the dense tower is moved / cast -- a blanket ``.to(bf16)`` would materialise a second copy
+    held = {k: emb._buffers[k] for k in ("table", "accumulator")}
+    for k in held:
+        emb._buffers[k] = None
+    anchor = emb._anchor.data
     model = model.to(device)
     if device.type == "cuda":
-        # dense tower in bf16; tables and accumulators stay fp32
-        tab, acc, off = emb.table, emb.accumulator, emb.table_offsets
-        model = model.to(torch.bfloat16)
-        emb.table, emb.accumulator, emb.table_offsets = tab.float(), (acc.float() if acc is not None else None), off
-        emb._anchor.data = emb._anchor.data.float()
+        model = model.to(torch.bfloat16)      # dense tower in bf16; tables and accumulators stay fp32
+        emb.table_offsets = emb.table_offsets.to(torch.int64)
+        emb._anchor.data = anchor.to(device).float()
+    for k, v in held.items():
+        emb._buffers[k] = None if v is None else v.to(device)
     return model
 
 

@@ -79,6 +79,7 @@ template <int GDT>
 __global__ __launch_bounds__(256) void emb_chunk_partial_kernel(const void* __restrict__ grad,
                                                                 const int64_t* __restrict__ perm,
                                                                 const int64_t* __restrict__ chunk_begin,
+                                                                const int64_t* __restrict__ sorted_ids,
                                                                 float* __restrict__ partial, int64_t n, int D,
                                                                 int bag) {
     const int dv = (D + 7) >> 3;
@@ -91,6 +92,14 @@ __global__ __launch_bounds__(256) void emb_chunk_partial_kernel(const void* __re
         const int64_t j0 = chunk_begin[c];
         if (j0 >= n) continue;                       // beyond the last chunk
         const int64_t j1 = chunk_begin[c + 1];
+        // a chunk that IS its whole run (unique or rarely repeated ids: almost every row of an HBM-sized table) has no
+        // slab: the apply kernel sums those few gradient rows itself -- no fp32 round trip through `partial`
+        {
+            const int64_t id = sorted_ids[j0];
+            const bool starts = j0 == 0 || sorted_ids[j0 - 1] != id;
+            const bool ends = j1 >= n || sorted_ids[j1] != id;
+            if (starts && ends) continue;
+        }
         float acc[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = 0.f;
@@ -289,6 +298,7 @@ __global__ __launch_bounds__(PLAN_T) void plan_emit_kernel(const int64_t* __rest
 struct EmbApplyArgs {
     void* table; float* acc;                       // acc: [R, D] (Adagrad) or [R] (row-wise) or null
     const float* partial;
+    const void* grad; const int64_t* perm; const int64_t* chunk_begin; int bag;
     const int64_t* sorted_ids; const int64_t* seg_begin; const int64_t* seg_first_chunk;
     const int64_t* nchunks_ptr;                    // device scalar: number of chunks
     int64_t n, R; int D, opt;
@@ -296,7 +306,7 @@ struct EmbApplyArgs {
 };
 
 // (a.2) one lane group per unique id: g = ordered sum of its chunk slabs, then the optimizer.
-template <int TDT>
+template <int TDT, int GDT>
 __global__ __launch_bounds__(256) void emb_segment_apply_kernel(EmbApplyArgs a) {
     const int D = a.D;
     const int dv = (D + 7) >> 3;
@@ -314,9 +324,42 @@ __global__ __launch_bounds__(256) void emb_segment_apply_kernel(EmbApplyArgs a) 
         const int64_t c0 = a.seg_first_chunk[s];
         int64_t c1 = a.seg_first_chunk[s + 1];
         if (c1 > nchunks) c1 = nchunks;
+        // the row's weights (and Adagrad accumulator) are requested FIRST: their addresses need only the id, so the
+        // random HBM row fetches overlap with the perm -> gradient-row chain below instead of following it
+        float w[8], h[8];
+        const int64_t off = row * D + (v << 3);
+        if (vec) load8<TDT>(a.table, off, w);
+        else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = ((v << 3) + k < D) ? load1<TDT>(a.table, off + k) : 0.f;
+        }
+        if (a.opt == EMB_OPT_ADAGRAD) {
+            if (vec) load8<DTF_F32>(a.acc, off, h);
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) h[k] = ((v << 3) + k < D) ? a.acc[off + k] : 0.f;
+            }
+        }
         float g[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) g[k] = 0.f;
+        if (c1 - c0 == 1) {
+            // single-chunk run: the gradient rows straight from `grad`, in sorted order (bitwise the slab's sum)
+            const int64_t j1 = a.chunk_begin[c0 + 1];
+            for (int64_t j = j0; j < j1; ++j) {
+                const int64_t src = a.perm[j] / a.bag;
+                if (vec) {
+                    float x[8];
+                    load8<GDT>(a.grad, src * D + (v << 3), x);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) g[k] += x[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if ((v << 3) + k < D) g[k] += load1<GDT>(a.grad, src * D + (v << 3) + k);
+                }
+            }
+        } else
         for (int64_t c = c0; c < c1; ++c) {
             if (vec) {
                 float x[8];
@@ -329,25 +372,12 @@ __global__ __launch_bounds__(256) void emb_segment_apply_kernel(EmbApplyArgs a) 
                     if ((v << 3) + k < D) g[k] += a.partial[c * D + (v << 3) + k];
             }
         }
-        float w[8];
-        const int64_t off = row * D + (v << 3);
-        if (vec) load8<TDT>(a.table, off, w);
-        else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = ((v << 3) + k < D) ? load1<TDT>(a.table, off + k) : 0.f;
-        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) g[k] = fmaf(g[k], a.grad_scale, a.wd * w[k]);
         if (a.opt == EMB_OPT_SGD) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) w[k] = fmaf(-a.lr, g[k], w[k]);
         } else if (a.opt == EMB_OPT_ADAGRAD) {
-            float h[8];
-            if (vec) load8<DTF_F32>(a.acc, off, h);
-            else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) h[k] = ((v << 3) + k < D) ? a.acc[off + k] : 0.f;
-            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 h[k] = fmaf(g[k], g[k], h[k]);
@@ -456,16 +486,16 @@ int dtf_embedding_sparse_apply(void* table, int table_dtype, float* acc, const v
     const int grid = dtf_stream_grid(n * dv, 256);
     if (grad_dtype == DTF_BF16)
         hipLaunchKernelGGL((emb_chunk_partial_kernel<DTF_BF16>), dim3(grid), dim3(256), 0, stream, grad, perm,
-                           chunk_begin, partial, n, D, bag);
+                           chunk_begin, sorted_ids, partial, n, D, bag);
     else
         hipLaunchKernelGGL((emb_chunk_partial_kernel<DTF_F32>), dim3(grid), dim3(256), 0, stream, grad, perm,
-                           chunk_begin, partial, n, D, bag);
-    EmbApplyArgs a{table, acc, partial, sorted_ids, seg_begin, seg_first_chunk, nchunks_ptr, n, R, D, opt,
-                   lr, eps, grad_scale, wd};
-    if (table_dtype == DTF_BF16)
-        hipLaunchKernelGGL((emb_segment_apply_kernel<DTF_BF16>), dim3(grid), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((emb_segment_apply_kernel<DTF_F32>), dim3(grid), dim3(256), 0, stream, a);
+                           chunk_begin, sorted_ids, partial, n, D, bag);
+    EmbApplyArgs a{table, acc, partial, grad, perm, chunk_begin, bag, sorted_ids, seg_begin, seg_first_chunk,
+                   nchunks_ptr, n, R, D, opt, lr, eps, grad_scale, wd};
+#define APPLY(T, G) hipLaunchKernelGGL((emb_segment_apply_kernel<T, G>), dim3(grid), dim3(256), 0, stream, a)
+    if (table_dtype == DTF_BF16) { if (grad_dtype == DTF_BF16) APPLY(DTF_BF16, DTF_BF16); else APPLY(DTF_BF16, DTF_F32); }
+    else { if (grad_dtype == DTF_BF16) APPLY(DTF_F32, DTF_BF16); else APPLY(DTF_F32, DTF_F32); }
+#undef APPLY
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -185,6 +185,88 @@ class _Task:
         self.hbm_during = None     # one hipMemGetInfo sample while the task runs
 
 
+ENTRY_IMAGE = "distributed_tensorflow_amd.service.entry"
+
+
+class _WarmPool:
+    """A few task processes started ahead of time (``service/warm_worker.py``): interpreter up, torch and this
+    package imported, HIP untouched.  ``take()`` hands one out (or None when none is ready -- the caller then
+    starts a cold process); the pool refills in the background."""
+
+    def __init__(self, size, python, env, root):
+        self.size, self._python, self._env, self._root = int(size), python, dict(env), root
+        self._refill_delay = 3.0
+        self._ready = []
+        self._starting = 0
+        self._lock = threading.Lock()
+        self._closed = False
+        for _ in range(self.size):
+            self._spawn_async()
+
+    def _spawn_async(self):
+        with self._lock:
+            if self._closed or len(self._ready) + self._starting >= self.size:
+                return
+            self._starting += 1
+        threading.Thread(target=self._spawn, name="warm-spawn", daemon=True).start()
+
+    def _spawn(self):
+        p = None
+        try:
+            env = dict(self._env)
+            env["PYTHONPATH"] = self._root + os.pathsep + env.get("PYTHONPATH", "")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            p = subprocess.Popen([self._python, "-u", "-m", "distributed_tensorflow_amd.service.warm_worker"], env=env,
+                                 stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
+            line = p.stdout.readline()          # "WARM <pid>": imports done
+            if not line.startswith(b"WARM"):
+                raise RuntimeError("warm worker did not come up")
+        except Exception:       # noqa: BLE001 -- a pool that cannot fill just means cold starts
+            log.exception("warm worker failed to start")
+            if p is not None:
+                p.kill()
+            p = None
+        with self._lock:
+            self._starting -= 1
+            if p is not None and not self._closed:
+                self._ready.append(p)
+                p = None
+        if p is not None:
+            p.kill()
+
+    def take(self):
+        with self._lock:
+            while self._ready:
+                p = self._ready.pop(0)
+                if p.poll() is None:
+                    break
+                p = None
+            else:
+                p = None
+        # refill, but not while the task that was just handed out is starting (imports are CPU-heavy)
+        for _ in range(2 if p is not None else 1):
+            timer = threading.Timer(self._refill_delay, self._spawn_async)
+            timer.daemon = True
+            timer.start()
+        return p
+
+    def ready(self):
+        with self._lock:
+            return len(self._ready)
+
+    def close(self):
+        with self._lock:
+            self._closed = True
+            procs, self._ready = self._ready, []
+        for p in procs:
+            try:
+                p.stdin.close()
+                p.kill()
+            except OSError:
+                pass
+
+
 class LocalCluster:
     def __init__(self, gpus=None, log_dir=None, python=None, extra_env=None, cfg=None):
         cfg = cfg or ApiConfig()
@@ -218,6 +300,12 @@ class LocalCluster:
         self._sample_after = cfg.getfloat("launcher", "hbm_sample_after_seconds", 4.0)
         if self._verify:
             threading.Thread(target=self._probe_idle_baseline, name="hbm-baseline", daemon=True).start()
+        # warm rank pool: only for the framework's own entry module (a custom image starts cold)
+        n_warm = cfg.getint("launcher", "warm_pool", 0)
+        self._root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        self._warm = None
+        if n_warm > 0 and cfg.get("image", "tensorflow") == ENTRY_IMAGE:
+            self._warm = _WarmPool(n_warm, self._python, dict(os.environ, **self._extra_env), self._root)
 
     # ------------------------------------------------------------------ DNS
     def _alloc_port(self):
@@ -391,12 +479,27 @@ class LocalCluster:
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
         os.makedirs(self._log_dir, exist_ok=True)
         t.log_path = os.path.join(self._log_dir, t.name + ".log")
-        logf = open(t.log_path, "ab", buffering=0)
-        try:
-            t.proc = subprocess.Popen(cmd, env=env, stdout=logf, stderr=subprocess.STDOUT,
-                                      stdin=subprocess.DEVNULL, start_new_session=True)
-        finally:
-            logf.close()
+        warm = self._warm.take() if (self._warm is not None and image == ENTRY_IMAGE) else None
+        if warm is not None:
+            # a pre-started process becomes the task: it only needs what differs from the launcher's own environment
+            delta = {k: v for k, v in env.items() if os.environ.get(k) != v}
+            try:
+                warm.stdin.write((json.dumps({"argv": [str(a) for a in args], "env": delta,
+                                              "log": t.log_path}) + "\n").encode())
+                warm.stdin.flush()
+                warm.stdin.close()
+                t.proc = warm
+                t.status["warm"] = True
+            except OSError:
+                warm.kill()
+                warm = None
+        if warm is None:
+            logf = open(t.log_path, "ab", buffering=0)
+            try:
+                t.proc = subprocess.Popen(cmd, env=env, stdout=logf, stderr=subprocess.STDOUT,
+                                          stdin=subprocess.DEVNULL, start_new_session=True)
+            finally:
+                logf.close()
         t.status.update(active=1, phase="Running", startTime=time.time())
         self._emit("MODIFIED", t)
         threading.Thread(target=self._reap, args=(t,), name="wait-" + t.name, daemon=True).start()
@@ -614,6 +717,8 @@ class LocalCluster:
             self._closed = True
             tasks = list(self._jobs.values())
             self._cv.notify_all()
+        if self._warm is not None:
+            self._warm.close()
         for t in tasks:
             t.deleted = True
             self._kill(t)

@@ -171,15 +171,26 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
 def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_dir, export_dir, metrics,
              t_start=None):
     t_start = t_start or time.time()
+    trace = os.environ.get("DTF_TRACE_START", "0") == "1"
+
+    def mark(what):
+        if trace:
+            print("[start +%.3f s] %s" % (time.time() - t_start, what), flush=True)
     mod = get_model_module(opts.model)
     use_cuda = torch.cuda.is_available() and int(os.environ.get("DTF_NUM_GPUS", "1")) > 0
     device = torch.device("cuda", 0) if use_cuda else torch.device("cpu")
     torch.manual_seed(opts.seed)
+    if not use_cuda and num_workers + num_ps > 1 and "OMP_NUM_THREADS" not in os.environ:
+        # CPU ranks of one job share the host: without a cap every rank spins cpu_count() threads
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // (num_workers + num_ps)))
     # the colocated asynchronous mode uses NO collective in the step (one-sided applies over peer-mapped shards):
     # its process group is control-plane only, and gloo lets several ranks share a GPU
     one_sided = placement != "dedicated" and opts.update_mode == "async"
-    comm = Comm.from_env(device, backend="gloo" if one_sided else None)
+    # DTF_FORCE_COMM=1: keep a live process group even with one rank (the collectives then really run: 1-GPU rehearsal)
+    comm = Comm.from_env(device, backend="gloo" if one_sided else None,
+                         force=bool(int(os.environ.get("DTF_FORCE_COMM", "0"))) and not one_sided)
     chief = job_name == "worker" and task_index == 0
+    mark("communicator ready")
     if chief:
         metrics(t_comm_ready=time.time())
     wire = _wire_dtype(opts, device)
@@ -220,6 +231,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
 
     # ------------------------------------------------------------ worker task
     model = prepare_model(mod, opts, device, comm)
+    mark("model built on the device")
     named = list(model.named_parameters())
     if placement == "dedicated":
         from ..parallel.dedicated_ps import PSWorkerClient
@@ -240,6 +252,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     print("[worker %d] PS runtime: %s, update_mode=%s, shard groups=%d, push=%s" % (
         task_index, type(ps).__name__, ps.update_mode, getattr(ps, "num_shards", num_ps), getattr(ps, "push", "-")),
         flush=True)
+    mark("PS runtime ready")
     tf_names = mod.tf_variable_names(model) if hasattr(mod, "tf_variable_names") else {}
     start_step = 0
     if opts.resume and do_ckpt and placement != "dedicated" and ckpt.latest_step(export) is not None:
@@ -249,6 +262,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     if getattr(mod, "NEEDS_COMM", False):
         bkw["model"] = model
     batch = mod.synthetic_batch(opts.batch, device=device, seed=opts.seed + 1 + task_index, **bkw)
+    mark("synthetic batch on the device")
     fault = _parse_fault(opts.fault)
     first = {"done": False}
 

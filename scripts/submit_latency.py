@@ -37,6 +37,11 @@ def main():
     ap.add_argument("--workers", type=int, default=1)
     ap.add_argument("--ps", type=int, default=1)
     ap.add_argument("--update-mode", default="sync")
+    ap.add_argument("--placement", default="")
+    ap.add_argument("--staleness", type=int, default=1)
+    ap.add_argument("--warm", type=int, default=0, help="size of the launcher's warm rank pool (0 = cold starts)")
+    ap.add_argument("--cpu", action="store_true", help="CPU / gloo job (no amd.com/gpu request)")
+    ap.add_argument("--extra", default="", help="extra query string for the job's file URI, e.g. image_size=64")
     ap.add_argument("--fault", default="")
     ap.add_argument("--cancel-after", type=float, default=0.0, help="DELETE the job this many seconds after step 1")
     ap.add_argument("--timeout", type=float, default=600)
@@ -44,12 +49,28 @@ def main():
     a = ap.parse_args()
 
     ApiConfig.override("launcher", "grace_seconds", "3")
-    ngpu = visible_gpu_count()
+    ApiConfig.override("launcher", "warm_pool", str(a.warm))
+    ngpu = 0 if a.cpu else visible_gpu_count()
     gpus = list(range(min(ngpu, a.workers))) if ngpu else []
     hbm0 = hbm_used_bytes()
     aio = AllInOne(gpus=gpus, log_dir=os.path.join("gpurun_out", "tasks"))
     port = aio.start(port=0)
-    q = "steps=%d&batch=%d&update_mode=%s&log_every=10" % (a.steps, a.batch, a.update_mode)
+    if a.warm:
+        t_w = time.time()
+        while aio.cluster._warm is not None and aio.cluster._warm.ready() < min(a.warm, a.workers + a.ps) \
+                and time.time() - t_w < 180:
+            time.sleep(0.05)
+        print("[submit] warm pool ready (%d) after %.1f s" % (aio.cluster._warm.ready(), time.time() - t_w), flush=True)
+    if gpus:
+        # the idle-device baseline of the HBM verification is probed at service start; let it finish first
+        t_w = time.time()
+        while not aio.cluster._idle_used and time.time() - t_w < 60:
+            time.sleep(0.05)
+    q = "steps=%d&batch=%d&update_mode=%s&staleness=%d&log_every=10" % (a.steps, a.batch, a.update_mode, a.staleness)
+    if a.placement:
+        q += "&placement=" + a.placement
+    if a.extra:
+        q += "&" + a.extra
     if a.fault:
         q += "&fault=" + a.fault
     spec = {"type": "tensorflow", "file": "builtin://%s?%s" % (a.model, q), "data": "/synthetic",
@@ -59,7 +80,11 @@ def main():
     t_resp = time.time()
     uid = parse_task_name(names[0])[0]
     out = {"uid": uid, "tasks": names, "post_roundtrip_s": round(t_resp - t_post, 4), "model": a.model,
-           "gpus": gpus, "hbm_used_before_mb": [b >> 20 for b in hbm0]}
+           "gpus": gpus, "workers": a.workers, "ps": a.ps, "update_mode": a.update_mode, "warm_pool": a.warm,
+           "batch": a.batch, "force_comm": os.environ.get("DTF_FORCE_COMM", "0"),
+           "idle_baseline_mb": {g: u >> 20 for g, u in aio.cluster._idle_used.items()}}
+    if any(hbm0):
+        out["hbm_used_before_mb"] = [b >> 20 for b in hbm0]
     print("[submit] %s -> %s" % (uid, names), flush=True)
     deadline = time.time() + a.timeout
     step1 = None
@@ -76,7 +101,8 @@ def main():
             out["spawn_s"] = round(float(m["t_spawned"]) - float(m["t_submit"]), 4)
             print("[submit] first step %.3f s after submit" % step1, flush=True)
             hb = hbm_used_bytes()
-            out["hbm_used_during_mb"] = [b >> 20 for b in hb]
+            if any(hb):
+                out["hbm_used_during_mb"] = [b >> 20 for b in hb]
         if step1 is not None and a.cancel_after and not cancelled and time.time() - t_post > step1 + a.cancel_after:
             print("[submit] cancelling job", flush=True)
             http(port, "DELETE", "/v1/train?uid=" + uid)
@@ -97,7 +123,9 @@ def main():
         out["submit_to_cleaned_s"] = round(float(rec["t_cleaned"]) - float(m.get("t_submit", t_post)), 3)
     out["hbm_reclaim"] = rec.get("hbm_reclaim") or aio.cluster.reclaim_reports
     time.sleep(0.5)
-    out["hbm_used_after_mb"] = [b >> 20 for b in hbm_used_bytes()]
+    hb = hbm_used_bytes()
+    if any(hb):
+        out["hbm_used_after_mb"] = [b >> 20 for b in hb]
     out["jobs_left"] = [j["metadata"]["name"] for j in aio.cluster.list_namespaced_job("default")["items"]]
     out["services_left"] = list(aio.cluster.dns_map(uid))
     aio.stop()

@@ -216,3 +216,31 @@ def test_jobspec_file_field():
     assert kind == "script" and path == __file__
     with pytest.raises(ValueError):
         parse_file_field("/xxx/")          # the reference's sample value is neither
+
+
+def test_warm_rank_pool_adopts_a_task(tmp_path):
+    """[launcher] warm_pool: a process that has already imported torch + the package becomes the task (one JSON line
+    on its stdin: argv, environment delta, log file); exit code, log and lifecycle events are those of a cold task."""
+    ApiConfig.override("launcher", "warm_pool", "2")
+    ApiConfig.override("launcher", "verify_reclaim", "0")
+    c = LocalCluster(gpus=[], log_dir=str(tmp_path), extra_env={"PYTHONPATH": ROOT, "DTF_REDIS_PORT": "1"})
+    try:
+        assert c._warm is not None
+        assert _wait(lambda: c._warm.ready() == 2, 120), "warm workers did not come up"
+        info = {"file": "builtin://mnist_mlp?steps=3&batch=16&log_every=1", "resource": {"gpu": 0},
+                "detail": {"ps": 0, "worker": 1}}
+        c.create_namespaced_service("default", manifest.gen_service(UID, "worker", 0, 1))
+        t0 = time.time()
+        j = c.create_namespaced_job("default", manifest.gen_job(UID, "worker", 0, 1, info, "",
+                                                                "tf-%s-worker-0-1:2222" % UID))
+        name = j["metadata"]["name"]
+        assert j["status"].get("warm") is True
+        assert _wait(lambda: c.read_namespaced_job(name, "default")["status"]["succeeded"] == 1, 120), \
+            open(os.path.join(str(tmp_path), name + ".log")).read()[-2000:]
+        took = time.time() - t0
+        text = open(os.path.join(str(tmp_path), name + ".log")).read()
+        assert "[warm] pid" in text and "[train] step 3" in text
+        assert _wait(lambda: c._warm.ready() == 2, 120), "the pool must refill"
+        print("warm task wall time %.2f s" % took)
+    finally:
+        c.shutdown()
