@@ -47,14 +47,20 @@ def headers():
     return tuple(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
 
 
-def build(force=False, verbose=True, save_temps=False):
+def build(force=False, verbose=True, save_temps=False, debug_bounds=False):
+    """``debug_bounds``: compile with -DDTF_DEBUG_BOUNDS into ``libdtf_hip_debug.so`` (own object directory); run a
+    process against it with ``DTF_HIP_LIB=<path>`` -- see ``scripts/gpu_debug_bounds.sh``."""
+    global OBJ, LIB
+    if debug_bounds:
+        OBJ, LIB = os.path.join(HERE, "_build_debug"), os.path.join(HERE, "libdtf_hip_debug.so")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = headers()
     jobs = []
     for src in sources():
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         if force or _newer(src, obj, hdrs):
-            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + FLAGS + (["-DDTF_DEBUG_BOUNDS"] if debug_bounds else []) + \
+                EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
             if save_temps:
                 cmd += ["-save-temps=obj"]
             jobs.append((src, cmd))
@@ -84,4 +90,4 @@ def build(force=False, verbose=True, save_temps=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv)
+    build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, debug_bounds="--debug-bounds" in sys.argv)

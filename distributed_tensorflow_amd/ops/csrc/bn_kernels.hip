@@ -26,8 +26,17 @@
 #define BN_CT 64          // channels per block tile
 #define BN_ROWS 32        // rows per block iteration
 #define BN_UNROLL 4
+#define BN_REV_DEFAULT 0
 
 enum { BN_FWD_STATS = 0, BN_BWD_RELU_X = 1, BN_BWD_PLAIN = 2, BN_BWD_RELU_MASK = 3 };
+
+// Traversal order of the row chunks, per pass (bit set = descending).  Every tensor is streamed twice in a row
+// (statistics then apply; backward reduce then backward apply); the 256 MiB Infinity Cache keeps the most recently
+// touched ~256 MB, so a second pass that walks the rows in the OPPOSITE direction starts on lines that are still
+// on-die instead of chasing its own evictions.  bit 0: forward statistics, 1: forward apply, 2: backward reduce,
+// 3: backward apply.  Set once from DTF_BN_REV (host) before the first launch.
+__constant__ int bn_rev_mask = 0;
+#define BN_BX(BIT) (((bn_rev_mask >> (BIT)) & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x)
 // how the backward kernels learn the ReLU mask:
 //   RELU_X    recompute  fma(x, scale, shift) > 0  -- bitwise the forward's own decision,
 //             no extra tensor read (BN+ReLU without residual)
@@ -81,7 +90,8 @@ __device__ __forceinline__ void pool_gather_dy(const PoolGeom& g, int64_t row, i
         const unsigned kh = (unsigned)(h + g.pad - oh * g.stride);
         for (int ow = ow_lo; ow <= ow_hi; ++ow) {
             const unsigned me = kh * (unsigned)g.K + (unsigned)(w + g.pad - ow * g.stride);
-            const int64_t o = (((int64_t)n * g.OH + oh) * g.OW + ow) * C + c0;
+            const int64_t o = DTF_IDX((((int64_t)n * g.OH + oh) * g.OW + ow) * C + c0,
+                                      (int64_t)(n + 1) * g.OH * g.OW * C, "bn pool-gather window");
             const u32x2 pk = *reinterpret_cast<const u32x2*>(g.tap + o);
             float v[8];
             ld8bf(g.dyp + o, v);
@@ -113,7 +123,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     const bool cvalid = c0 < C;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int bx = BN_BX(MODE == BN_FWD_STATS ? 0 : 2);
+    const int64_t r0 = (int64_t)bx * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     float s1[8], s2[8], mu[8], sc[8], sh[8];
@@ -144,6 +155,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                 const int64_t row = r + (int64_t)u * BN_ROWS;
                 ok[u] = row < r1;
                 if (ok[u]) {
+                    (void)DTF_IDX(row, M, "bn_reduce row");
+                    (void)DTF_IDX(c0 + 7, C, "bn_reduce channel");
                     ld8bf(x + row * ldx + c0, xv[u]);
                     if (MODE != BN_FWD_STATS) {
                         if (POOL) pool_gather_dy(pg, row, C, c0, dv[u]);
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
         const int c = blockIdx.y * BN_CT + cc;
         if (c < C) {
             float s = red[0][stat][cc] + red[1][stat][cc] + red[2][stat][cc] + red[3][stat][cc];
-            partial[((int64_t)blockIdx.x * 2 + stat) * C + c] = s;
+            partial[((int64_t)bx * 2 + stat) * C + c] = s;
         }
     }
 }
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const unsigned short*
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     if (c0 >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r0 = (int64_t)BN_BX(1) * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     float sc[8], sh[8];
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     if (c0 >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r0 = (int64_t)BN_BX(3) * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     float k1[8], k2[8], k3[8], sc[8], sh[8];
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(256) void bn2_fwd_apply_kernel(const unsigned short
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     if (c0 >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r0 = (int64_t)BN_BX(1) * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     float sa[8], ha[8], sb[8];
@@ -490,7 +503,8 @@ __global__ __launch_bounds__(256) void bn2_bwd_reduce_kernel(const unsigned shor
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     const bool cvalid = c0 < C;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int bx = BN_BX(2);
+    const int64_t r0 = (int64_t)bx * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     float s1[8], s2a[8], s2b[8], ma[8], mb[8];
@@ -554,12 +568,12 @@ __global__ __launch_bounds__(256) void bn2_bwd_reduce_kernel(const unsigned shor
         if (c < C) {
             const float v = red[0][stat][cc] + red[1][stat][cc] + red[2][stat][cc] + red[3][stat][cc];
             if (stat == 0) {
-                partial_a[((int64_t)blockIdx.x * 2 + 0) * C + c] = v;
-                partial_b[((int64_t)blockIdx.x * 2 + 0) * C + c] = v;
+                partial_a[((int64_t)bx * 2 + 0) * C + c] = v;
+                partial_b[((int64_t)bx * 2 + 0) * C + c] = v;
             } else if (stat == 1) {
-                partial_a[((int64_t)blockIdx.x * 2 + 1) * C + c] = v;
+                partial_a[((int64_t)bx * 2 + 1) * C + c] = v;
             } else {
-                partial_b[((int64_t)blockIdx.x * 2 + 1) * C + c] = v;
+                partial_b[((int64_t)bx * 2 + 1) * C + c] = v;
             }
         }
     }
@@ -576,7 +590,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const unsigned short
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     if (c0 >= C) return;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r0 = (int64_t)BN_BX(3) * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
     float a1[8], a2[8], a3[8], b1[8], b2[8], b3[8];
@@ -643,7 +657,22 @@ static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, i
     *ctiles = ct;
 }
 
+static void bn_init_order() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* e = getenv("DTF_BN_REV");
+    const int v = e ? atoi(e) : BN_REV_DEFAULT;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(bn_rev_mask), &v, sizeof(int));
+}
+
 extern "C" {
+
+// A/B switch for the traversal order (see bn_rev_mask); call before the next launch
+void dtf_bn_set_order(int mask) {
+    bn_init_order();
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(bn_rev_mask), &mask, sizeof(int));
+}
 
 // workspace query: floats needed for the partial sums of an [M, C] reduction
 int64_t dtf_bn_partial_floats(int64_t M, int C) {
@@ -680,6 +709,7 @@ int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const 
     // ldy: row stride (elements) of y -- C for a dense tensor, the total channel count when y is a
     // channel slice of a wider NHWC tensor (branch outputs written straight into a concat buffer)
     DTF_CLEAR_ERRORS();
+    bn_init_order();
     if (C % 8 != 0 || M <= 0) return -20;
     if (ldy == 0) ldy = C;
     if (ldx == 0) ldx = C;
@@ -710,6 +740,7 @@ int dtf_bn_stats_train(const void* x, const void* gamma, const void* beta, int p
                        float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                        float* partial, int64_t M, int C, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
+    bn_init_order();
     if (C % 8 != 0 || M <= 0) return -20;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
@@ -737,6 +768,7 @@ int dtf_bn_fwd_train_pre(const void* x, const void* res, void* y, void* mask, co
                          float* mean, float* invstd, float* scale, float* shift, const float* partial, int nblk,
                          int64_t M, int C, int relu, int64_t ldy, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
+    bn_init_order();
     if (C % 8 != 0 || M <= 0 || nblk <= 0) return -20;
     if (ldy == 0) ldy = C;
     if (ldy < C || (ldy & 7)) return -24;
@@ -761,6 +793,7 @@ int dtf_bn_fwd_train_pre(const void* x, const void* res, void* y, void* mask, co
 int dtf_bn_fwd_apply(const void* x, const void* res, void* y, void* mask, const float* scale, const float* shift,
                      int64_t M, int C, int relu, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
+    bn_init_order();
     if (C % 8 != 0 || M <= 0) return -20;
     if (relu && res && !mask) return -22;
     launch_fwd_apply(x, res, y, mask, scale, shift, M, C, relu, (int64_t)C, (int64_t)C, stream);
@@ -778,6 +811,7 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
     // lddx: row stride of dx (written into a channel slice of a wider gradient tensor when > C)
     // lddy: row stride (elements) of dy (a channel slice of the concat gradient is read in place)
     DTF_CLEAR_ERRORS();
+    bn_init_order();
     if (C % 8 != 0 || M <= 0) return -20;
     if (lddy == 0) lddy = C;
     if (ldx == 0) ldx = C;
@@ -818,6 +852,7 @@ int dtf_bn_bwd_train_pool(const void* dyp, const void* tap, const void* x, const
                           void* dgamma, void* dbeta, float* coef, float* partial, int N, int H, int W, int C, int OH, int OW,
                           int k, int stride, int pad, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
+    bn_init_order();
     const int64_t M = (int64_t)N * H * W;
     if (C % 8 != 0 || M <= 0 || M >= (1ll << 32) || stride < 1 || pad < 0 || pad >= k) return -20;
     if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return -21;
@@ -848,6 +883,7 @@ int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const
                       float* rv_b, float momentum_a, float eps_a, float momentum_b, float eps_b, float* stats_a,
                       float* stats_b, float* partial, int64_t M, int C, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
+    bn_init_order();
     if (C % 8 != 0 || M <= 0 || !mask) return -20;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
@@ -883,6 +919,7 @@ int dtf_bn2_bwd_train(const void* dy, const void* xa, const void* xb, const void
                       const void* gamma_b, int param_dtype, const float* stats_a, const float* stats_b, void* dxa, void* dxb,
                       void* dgb_a, void* dgb_b, float* coef, float* partial, int64_t M, int C, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
+    bn_init_order();
     if (C % 8 != 0 || M <= 0 || !mask) return -20;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);

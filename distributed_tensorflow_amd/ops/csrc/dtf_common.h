@@ -6,6 +6,26 @@
 
 #define DTF_WAVE 64
 
+// Debug build (`python -m distributed_tensorflow_amd.ops.build --debug-bounds` -> libdtf_hip_debug.so, selected with
+// DTF_HIP_LIB): DTF_IDX(i, limit, what) checks 0 <= i < limit at the places where an index is COMPUTED FROM DATA or from
+// a launch-geometry assumption (gathered rows, sorted-run boundaries, routed slots, tile edges, pooled windows).  A
+// violation prints one greppable line and the access is redirected to element 0, so the run finishes and reports
+// instead of faulting the device (no sanitizer / debugger runs on the GPU pool).  Release builds: the plain index.
+#ifdef DTF_DEBUG_BOUNDS
+#include <stdio.h>
+__device__ __forceinline__ long long dtf_idx_check(long long i, long long limit, const char* what, int line) {
+    if (i < 0 || i >= limit) {
+        printf("DTF_BOUNDS_VIOLATION %s line %d: index %lld not in [0, %lld) block (%u,%u) thread %u\n", what, line, i,
+               limit, blockIdx.x, blockIdx.y, threadIdx.x);
+        return 0;
+    }
+    return i;
+}
+#define DTF_IDX(i, limit, what) dtf_idx_check((long long)(i), (long long)(limit), what, __LINE__)
+#else
+#define DTF_IDX(i, limit, what) (i)
+#endif
+
 enum DtfDtype : int { DTF_F32 = 0, DTF_BF16 = 1 };
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;

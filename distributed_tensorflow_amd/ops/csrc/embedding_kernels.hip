@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void emb_chunk_partial_kernel(const void* __re
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[k] = 0.f;
         for (int64_t j = j0; j < j1; ++j) {
-            const int64_t src = perm[j] / bag;
+            const int64_t src = DTF_IDX(perm[j] / bag, n / bag, "emb_chunk_partial perm");
             if (vec) {
                 float x[8];
                 load8<GDT>(grad, src * D + (v << 3), x);
@@ -319,9 +319,9 @@ __global__ __launch_bounds__(256) void emb_segment_apply_kernel(EmbApplyArgs a) 
         const int v = (int)(t - s * dv);
         const int64_t j0 = a.seg_begin[s];
         if (j0 >= a.n) continue;                    // beyond the last unique id
-        const int64_t row = a.sorted_ids[j0];
+        const int64_t row = a.sorted_ids[DTF_IDX(j0, a.n, "emb_segment_apply seg_begin")];
         if (row < 0 || row >= a.R) continue;        // padding id: no update
-        const int64_t c0 = a.seg_first_chunk[s];
+        const int64_t c0 = DTF_IDX(a.seg_first_chunk[s], a.n + 1, "emb_segment_apply first chunk");
         int64_t c1 = a.seg_first_chunk[s + 1];
         if (c1 > nchunks) c1 = nchunks;
         // the row's weights (and Adagrad accumulator) are requested FIRST: their addresses need only the id, so the
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void emb_segment_apply_kernel(EmbApplyArgs a) 
             // single-chunk run: the gradient rows straight from `grad`, in sorted order (bitwise the slab's sum)
             const int64_t j1 = a.chunk_begin[c0 + 1];
             for (int64_t j = j0; j < j1; ++j) {
-                const int64_t src = a.perm[j] / a.bag;
+                const int64_t src = DTF_IDX(a.perm[j] / a.bag, a.n / a.bag, "emb_segment_apply perm");
                 if (vec) {
                     float x[8];
                     load8<GDT>(a.grad, src * D + (v << 3), x);

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(GemmArgs a) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] += r[k];
             }
-            store8<DTF_BF16>(a.Y, o, v);
+            store8<DTF_BF16>(a.Y, DTF_IDX(o, (int64_t)a.M * a.N - 7, "gemm128 epilogue store"), v);
         } else {
             for (int k = 0; k < 8 && gn + k < a.N; ++k) {
                 float x = v[k];
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
                                 v8[2 * k + 1] += __uint_as_float(rres[h][k] & 0xffff0000u);
                             }
                         }
-                        store8<DTF_BF16>(a.Y, (int64_t)om * a.N + on, v8);
+                        store8<DTF_BF16>(a.Y, DTF_IDX((int64_t)om * a.N + on, (int64_t)a.M * a.N - 7, "gemm256p epilogue store"), v8);
                     }
                 }
                 rres[0] = nres[0];

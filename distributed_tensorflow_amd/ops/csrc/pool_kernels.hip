@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
                 const int w = w0 + kw;
                 if (w < 0 || w >= W) continue;
                 float v[8];
-                load8<DTF_BF16>(xn, ((int64_t)h * W + w) * C, v);
+                load8<DTF_BF16>(xn, DTF_IDX(((int64_t)h * W + w) * C, (int64_t)H * W * C, "maxpool_fwd window"), v);
                 if (AFFINE) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f)));
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* 
             const unsigned kh = (unsigned)(h + pad - oh * stride);
             for (int ow = ow_lo; ow <= ow_hi; ++ow) {
                 const unsigned me = kh * K + (unsigned)(w + pad - ow * stride);
-                const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c8 * 8;
+                const int64_t o = DTF_IDX((((int64_t)n * OH + oh) * OW + ow) * C + c8 * 8, (int64_t)N * OH * OW * C,
+                                          "maxpool_bwd window");
                 const u32x2 pk = *reinterpret_cast<const u32x2*>(tap + o);
                 float g[8];
                 load8<DTF_BF16>(dy, o, g);

@@ -200,7 +200,7 @@ __device__ __forceinline__ int find_tensor(const PackTable& t, int chunk) {
 template <int FDT, bool UNPACK>
 __global__ __launch_bounds__(256) void bucket_pack_kernel(PackTable t, void* flat, float scale) {
     const int chunk = blockIdx.x;
-    const int ti = find_tensor(t, chunk);
+    const int ti = (int)DTF_IDX(find_tensor(t, chunk), t.ntensors, "bucket_pack tensor of chunk");
     const int64_t e0 = (int64_t)(chunk - t.chunk_start[ti]) * PACK_CHUNK;
     int64_t count = (int64_t)t.numel[ti] - e0;
     if (count > PACK_CHUNK) count = PACK_CHUNK;

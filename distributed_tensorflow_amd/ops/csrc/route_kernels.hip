@@ -45,7 +45,7 @@ struct RouteArgs {
 __device__ __forceinline__ int route_owner(const RouteArgs& a, int64_t g, int64_t& local) {
     if (g < 0 || g >= a.total_rows) { local = -1; return -1; }
     if (a.div) {
-        int o = (int)(g / a.rows_per);
+        int o = (int)DTF_IDX(g / a.rows_per, a.W, "route div owner");
         local = g - (int64_t)o * a.rows_per;
         return o;
     }
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void route_scatter_kernel(RouteArgs a,
                 int64_t p = running[o] + rank;
                 for (int w = 0; w < wave; ++w) p += wcnt[w][o];
                 if (p < a.cap) {
-                    const int64_t s = (int64_t)o * a.cap + p;
+                    const int64_t s = DTF_IDX((int64_t)o * a.cap + p, (int64_t)a.W * a.cap, "route slot");
                     a.send_ids[s] = local;
                     a.inv[s] = i;
                     a.slot[i] = s;

