@@ -26,17 +26,21 @@
 #define BN_CT 64          // channels per block tile
 #define BN_ROWS 32        // rows per block iteration
 #define BN_UNROLL 4
-#define BN_REV_DEFAULT 0
 
 enum { BN_FWD_STATS = 0, BN_BWD_RELU_X = 1, BN_BWD_PLAIN = 2, BN_BWD_RELU_MASK = 3 };
 
-// Traversal order of the row chunks, per pass (bit set = descending).  Every tensor is streamed twice in a row
-// (statistics then apply; backward reduce then backward apply); the 256 MiB Infinity Cache keeps the most recently
-// touched ~256 MB, so a second pass that walks the rows in the OPPOSITE direction starts on lines that are still
-// on-die instead of chasing its own evictions.  bit 0: forward statistics, 1: forward apply, 2: backward reduce,
-// 3: backward apply.  Set once from DTF_BN_REV (host) before the first launch.
-__constant__ int bn_rev_mask = 0;
-#define BN_BX(BIT) (((bn_rev_mask >> (BIT)) & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x)
+// Row-chunk schedule.  rows_per_block > 0: block b owns the contiguous rows [b * rows_per_block, ...) (round 1).
+// rows_per_block == 0 ("sweep", the default): the grid walks the tensor together -- block b takes chunks b,
+// b + gridDim.x, ... of BN_ROWS * U rows, so at any moment the resident blocks read ONE window of adjacent rows.
+// With 768 private ranges the chip streamed from 768 scattered places at once and lost DRAM page locality: measured
+// on a cold [802816 x 256] bf16 pass (x, residual -> y): 249 us vs 194-216 us (scripts/ubench/stream_variants.hip,
+// profiles/r2_bn_sweep_ab.txt).  Reduction order per block stays fixed -> statistics remain bitwise reproducible.
+#define BN_SCHED(U)                                                                                          \
+    const bool sweep__ = rows_per_block == 0;                                                                \
+    const int64_t r0 = sweep__ ? (int64_t)blockIdx.x * (BN_ROWS * (U)) : (int64_t)blockIdx.x * rows_per_block; \
+    const int64_t rstep = sweep__ ? (int64_t)gridDim.x * (BN_ROWS * (U)) : (int64_t)(BN_ROWS * (U));          \
+    int64_t r1 = sweep__ ? M : r0 + rows_per_block;                                                          \
+    if (r1 > M) r1 = M;
 // how the backward kernels learn the ReLU mask:
 //   RELU_X    recompute  fma(x, scale, shift) > 0  -- bitwise the forward's own decision,
 //             no extra tensor read (BN+ReLU without residual)
@@ -123,10 +127,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     const bool cvalid = c0 < C;
-    const int bx = BN_BX(MODE == BN_FWD_STATS ? 0 : 2);
-    const int64_t r0 = (int64_t)bx * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    const int bx = blockIdx.x;
+    BN_SCHED(U)
     float s1[8], s2[8], mu[8], sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; sc[k] = 0.f; sh[k] = 0.f; }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
     }
     const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
     if (cvalid) {
-        for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * U) {
+        for (int64_t r = r0 + ty; r < r1; r += rstep) {
             float xv[U][8], dv[U][8];
             unsigned mb[U];
             bool ok[U];
@@ -330,14 +332,12 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const unsigned short*
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     if (c0 >= C) return;
-    const int64_t r0 = (int64_t)BN_BX(1) * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    BN_SCHED(BN_UNROLL)
     float sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
     unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
-    for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+    for (int64_t r = r0 + ty; r < r1; r += rstep) {
         float xv[BN_UNROLL][8], rv[BN_UNROLL][8];
         bool ok[BN_UNROLL];
 #pragma unroll
@@ -386,9 +386,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     if (c0 >= C) return;
-    const int64_t r0 = (int64_t)BN_BX(3) * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    BN_SCHED(BN_UNROLL)
     float k1[8], k2[8], k3[8], sc[8], sh[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -400,7 +398,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
         for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
     }
     const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
-    for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+    for (int64_t r = r0 + ty; r < r1; r += rstep) {
         float xv[BN_UNROLL][8], dv[BN_UNROLL][8];
         unsigned mb[BN_UNROLL];
         bool ok[BN_UNROLL];
@@ -451,9 +449,7 @@ __global__ __launch_bounds__(256) void bn2_fwd_apply_kernel(const unsigned short
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     if (c0 >= C) return;
-    const int64_t r0 = (int64_t)BN_BX(1) * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    BN_SCHED(BN_UNROLL)
     float sa[8], ha[8], sb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -462,7 +458,7 @@ __global__ __launch_bounds__(256) void bn2_fwd_apply_kernel(const unsigned short
         ha[k] = shift_a[c0 + k] + shift_b[c0 + k];
     }
     unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
-    for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+    for (int64_t r = r0 + ty; r < r1; r += rstep) {
         float av[BN_UNROLL][8], bv[BN_UNROLL][8];
         bool ok[BN_UNROLL];
 #pragma unroll
@@ -503,10 +499,8 @@ __global__ __launch_bounds__(256) void bn2_bwd_reduce_kernel(const unsigned shor
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     const bool cvalid = c0 < C;
-    const int bx = BN_BX(2);
-    const int64_t r0 = (int64_t)bx * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    const int bx = blockIdx.x;
+    BN_SCHED(BN_UNROLL)
     float s1[8], s2a[8], s2b[8], ma[8], mb[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2a[k] = 0.f; s2b[k] = 0.f; ma[k] = 0.f; mb[k] = 0.f; }
@@ -514,7 +508,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_reduce_kernel(const unsigned shor
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ma[k] = mean_a[c0 + k]; mb[k] = mean_b[c0 + k]; }
         const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
-        for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * BN_UNROLL) {
+        for (int64_t r = r0 + ty; r < r1; r += rstep) {
             float av[BN_UNROLL][8], bv[BN_UNROLL][8], dv[BN_UNROLL][8];
             unsigned mk[BN_UNROLL];
             bool ok[BN_UNROLL];
@@ -590,9 +584,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const unsigned short
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
     if (c0 >= C) return;
-    const int64_t r0 = (int64_t)BN_BX(3) * rows_per_block;
-    int64_t r1 = r0 + rows_per_block;
-    if (r1 > M) r1 = M;
+    BN_SCHED(2)
     float a1[8], a2[8], a3[8], b1[8], b2[8], b3[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -600,7 +592,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const unsigned short
         b1[k] = coef_b[c0 + k]; b2[k] = coef_b[C + c0 + k]; b3[k] = coef_b[2 * C + c0 + k];
     }
     const unsigned char* mrow = mask + ((int64_t)blockIdx.y * M) * 8 + tx;
-    for (int64_t r = r0 + ty; r < r1; r += BN_ROWS * 2) {
+    for (int64_t r = r0 + ty; r < r1; r += rstep) {
         float av[2][8], bv[2][8], dv[2][8];
         unsigned mk[2];
         bool ok[2];
@@ -634,6 +626,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const unsigned short
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+static int bn_sweep = -1;          // DTF_BN_SWEEP: 1 (default) grid-strided sweep, 0 private contiguous ranges
 static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, int* ctiles) {
     const int ct = (C + BN_CT - 1) / BN_CT;
     static int target = 0;
@@ -652,27 +645,24 @@ static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, i
     if (want > max_blocks) want = max_blocks;
     int64_t rpb = (M + want - 1) / want;
     rpb = (rpb + BN_ROWS - 1) / BN_ROWS * BN_ROWS;
-    *rows_per_block = (int)rpb;
     *nblk_x = (int)((M + rpb - 1) / rpb);
+    // the sweep pays on the big few-channel tensors (stem, stages 1-2); with >= 16 channel tiles a block row is a
+    // handful of blocks and private ranges measured 5-10 % faster
+    *rows_per_block = (bn_sweep == 0 || ct > 8) ? (int)rpb : 0;
     *ctiles = ct;
 }
 
 static void bn_init_order() {
-    static bool done = false;
-    if (done) return;
-    done = true;
-    const char* e = getenv("DTF_BN_REV");
-    const int v = e ? atoi(e) : BN_REV_DEFAULT;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(bn_rev_mask), &v, sizeof(int));
+    if (bn_sweep < 0) {
+        const char* e = getenv("DTF_BN_SWEEP");
+        bn_sweep = e ? (atoi(e) != 0) : 1;
+    }
 }
 
 extern "C" {
 
-// A/B switch for the traversal order (see bn_rev_mask); call before the next launch
-void dtf_bn_set_order(int mask) {
-    bn_init_order();
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(bn_rev_mask), &mask, sizeof(int));
-}
+// A/B switch of the row-chunk schedule (see BN_SCHED): 1 sweep, 0 private ranges
+void dtf_bn_set_sweep(int on) { bn_sweep = on ? 1 : 0; }
 
 // workspace query: floats needed for the partial sums of an [M, C] reduction
 int64_t dtf_bn_partial_floats(int64_t M, int C) {
