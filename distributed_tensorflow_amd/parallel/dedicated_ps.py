@@ -121,6 +121,14 @@ class PSServer(_Base):
             self.global_step += 1
 
     def _serve_async(self, poll_s=50e-6):
+        """One posted ``irecv`` per worker, served in arrival order.
+
+        RCCL requests are polled (``is_completed`` is an event query there).  A
+        gloo request only completes inside ``wait()``, so on gloo one waiter
+        thread per worker blocks in ``wait()`` and reports the arrival through a
+        queue; the apply loop itself stays single-threaded either way."""
+        import queue
+        import threading
         import time
 
         n = self.layout.shard_total
@@ -129,15 +137,40 @@ class PSServer(_Base):
         outbox = [torch.zeros(n, dtype=self.wire_dtype, device=self.device) for _ in range(W)]
         recv = [self.comm.irecv(inbox[w], P + w, tag=2) for w in range(W)]
         sent = [None] * W
+        polled = self.comm.backend == "nccl"
+        arrived = queue.Queue()
+
+        def waiter(w, req):
+            try:
+                req.wait()
+                arrived.put((w, None))
+            except Exception as e:                  # surfaced in the serving thread
+                arrived.put((w, e))
+
+        def post(w):
+            recv[w] = self.comm.irecv(inbox[w], P + w, tag=2)
+            if not polled:
+                threading.Thread(target=waiter, args=(w, recv[w]), daemon=True).start()
+
+        def ready():
+            if not polled:
+                w, err = arrived.get()
+                if err is not None:
+                    raise err
+                return [w]
+            out = [w for w in range(W) if recv[w] is not None and recv[w].is_completed()]
+            for w in out:
+                recv[w].wait()                      # orders the device work after the receive
+            if not out:
+                time.sleep(poll_s)
+            return out
+
+        if not polled:
+            for w in range(W):
+                threading.Thread(target=waiter, args=(w, recv[w]), daemon=True).start()
         live = W
         while live:
-            progressed = False
-            for w in range(W):
-                req = recv[w]
-                if req is None or not req.is_completed():
-                    continue
-                req.wait()                          # orders the device work after the receive (RCCL); no-op on gloo
-                progressed = True
+            for w in ready():
                 if float(inbox[w][n].item()) == DONE:
                     recv[w] = None
                     live -= 1
@@ -149,9 +182,7 @@ class PSServer(_Base):
                     sent[w].wait()                  # the previous reply to this worker has left its buffer
                 outbox[w].copy_(self.wire)
                 sent[w] = self.comm.isend(outbox[w], P + w, tag=3)
-                recv[w] = self.comm.irecv(inbox[w], P + w, tag=2)
-            if not progressed:
-                time.sleep(poll_s)
+                post(w)
         for h in sent:
             if h is not None:
                 h.wait()

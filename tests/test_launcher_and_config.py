@@ -244,3 +244,23 @@ def test_warm_rank_pool_adopts_a_task(tmp_path):
         print("warm task wall time %.2f s" % took)
     finally:
         c.shutdown()
+
+
+def test_placement_is_resolved_per_job_not_per_task():
+    """with placement=auto a GPU-less ps task used to choose 'dedicated' while its GPU workers chose
+    'colocated'.  Every task of a job now derives the placement from the job-level facts in its environment."""
+    from distributed_tensorflow_amd.service.entry import resolve_placement
+
+    info = {"file": "resnet50", "resource": {"gpu": 1}, "detail": {"ps": 1, "worker": 2}}
+    jobs = [manifest.gen_job(UID, t, 0, n, info, "a", "b") for t, n in (("ps", 1), ("worker", 2))]
+    envs = []
+    for j, own_gpus in zip(jobs, ("0", "1")):          # the ps task has no device of its own
+        env = {e["name"]: e["value"] for e in j["spec"]["template"]["spec"]["containers"][0]["env"]}
+        env["DTF_NUM_GPUS"] = own_gpus
+        envs.append(env)
+    assert [resolve_placement("auto", 1, e) for e in envs] == ["colocated", "colocated"]
+    # ps tasks with their own GPUs, or a CPU job with ps tasks: dedicated -- again for both task kinds
+    assert resolve_placement("auto", 2, {"DTF_JOB_WORKER_GPUS": "1", "DTF_JOB_PS_GPUS": "1", "DTF_NUM_GPUS": "0"}) == "dedicated"
+    assert resolve_placement("auto", 1, {"DTF_JOB_WORKER_GPUS": "0", "DTF_JOB_PS_GPUS": "0"}) == "dedicated"
+    assert resolve_placement("auto", 0, {"DTF_JOB_WORKER_GPUS": "0"}) == "colocated"
+    assert resolve_placement("dedicated", 1, envs[1]) == "dedicated"

@@ -54,7 +54,7 @@ def test_mnist_1ps_2workers_dedicated(aio, mode):
     a, port, tmp = aio
     export = str(tmp / ("export-" + mode))
     names = _post(port, {"type": "tensorflow", "export": export,
-                         "file": "builtin://mnist_mlp?steps=30&batch=64&update_mode=%s&log_every=10" % mode,
+                         "file": "builtin://mnist_mlp?steps=30&batch=64&update_mode=%s&log_every=10&placement=dedicated" % mode,
                          "detail": {"ps": 1, "worker": 2}})
     uid = parse_task_name(names[0])[0]
     rec = _wait_final(a, uid)
@@ -68,6 +68,32 @@ def test_mnist_1ps_2workers_dedicated(aio, mode):
     assert set(rd.names()) == {"hid_w", "hid_b", "sm_w", "sm_b"}
     assert tuple(rd.read("hid_w").shape) == (784, 100)
     assert rd.read("sm_b").abs().sum() > 0
+    # complete and consistently labelled: the step is the number of applies the PS performed (sync: one
+    # per step, async: one per worker per step), the shard file carries that label, and the chief's replicated state
+    # (global_step) was written before the index that publishes the checkpoint
+    assert rd.step == (30 if mode == "sync" else 60)
+    import os
+
+    assert os.path.exists(os.path.join(export, "model.ckpt-%d.data-00000-of-00001" % rd.step))
+    assert int(rd.replicated()["global_step"]) == rd.step
+    assert rd.index.get("placement") == "dedicated"
+
+
+def test_mnist_colocated_async_two_workers(aio):
+    """Colocated placement + update_mode=async on the CPU: the one-sided AsyncPS over mmap-ed shards (gloo for
+    control only), through the whole control plane."""
+    a, port, tmp = aio
+    names = _post(port, {"file": "builtin://mnist_mlp?steps=25&batch=32&placement=colocated&update_mode=async"
+                                 "&optimizer=momentum&lr=0.02",
+                         "export": str(tmp / "exp"), "detail": {"ps": 1, "worker": 2}})
+    uid = parse_task_name(names[0])[0]
+    rec = _wait_final(a, uid)
+    assert rec["status"] == "succeeded", _logs(a)
+    assert "PS runtime: AsyncPS" in _logs(a)
+    m = a.store.hgetall(uid + ":metrics")
+    assert float(m["final_loss"]) < float(m["first_loss"]), m
+    rd = CheckpointReader(str(tmp / "exp"))
+    assert rd.world == 2 and "hid_w/Momentum" in rd.names()
 
 
 def test_mnist_colocated_two_workers(aio):
