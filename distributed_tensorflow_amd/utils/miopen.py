@@ -8,6 +8,15 @@ resulting user find-db / perf-db (text) and kernel cache (``*.ukdb``) live in
 ``distributed_tensorflow_amd/miopen_db`` and :func:`setup` points MIOpen at a private
 writable copy of them.  This is what keeps job submit -> first step short (SURVEY 7.2
 item 2: never JIT or tune at submit time) without giving up the tuned kernels.
+
+Shapes that are NOT in the shipped databases (another batch size, another model) used to cost 13 s (ResNet-50) to
+36 s (Inception-v3) before the first step: MIOpen's heuristics picked Winograd / direct / GEMM solvers whose HIP and
+OpenCL sources it compiles at run time.  :func:`restrict_solvers` (called by :func:`setup`) leaves only the implicit-GEMM
+family enabled: composable_kernel instances compiled into the library plus MIOpen's shape-independent gfx950 assembly
+kernels, all of which the shipped kernel cache already holds (``scripts/gpu_miopen_widen.sh``).  Measured on MI355X,
+empty caches, batch 64 (``profiles/r2_miopen_cache_miss.txt``): first step 12.8 -> 2.6 s and 34.6 -> 5.0 s, steady state
++9 % / +20 % (the heuristics' non-igemm picks were also slower); neutral for the tuned batch-256 shapes, whose find-db
+entries are implicit-GEMM solvers anyway.
 """
 from __future__ import annotations
 
@@ -18,9 +27,23 @@ import tempfile
 _SRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "miopen_db"))
 
 
+_NON_IGEMM = ("MIOPEN_DEBUG_CONV_DIRECT", "MIOPEN_DEBUG_CONV_WINOGRAD", "MIOPEN_DEBUG_CONV_FFT", "MIOPEN_DEBUG_CONV_GEMM")
+
+
+def restrict_solvers():
+    """Disable the solver families that compile HIP / OpenCL at run time (see module docstring).  A value the user
+    exported wins; ``DTF_MIOPEN_ALL_SOLVERS=1`` leaves MIOpen's defaults alone."""
+    if os.environ.get("DTF_MIOPEN_ALL_SOLVERS", "0") == "1":
+        return False
+    for k in _NON_IGEMM:
+        os.environ.setdefault(k, "0")
+    return True
+
+
 def setup(force=False):
     """Call before the first convolution (ideally before ``import torch``).  Idempotent.
     Respects MIOPEN_USER_DB_PATH / MIOPEN_CUSTOM_CACHE_DIR if the user set them."""
+    restrict_solvers()
     if not force and ("MIOPEN_USER_DB_PATH" in os.environ or "MIOPEN_CUSTOM_CACHE_DIR" in os.environ):
         return os.environ.get("MIOPEN_USER_DB_PATH")
     if not os.path.isdir(_SRC) or not os.listdir(_SRC):

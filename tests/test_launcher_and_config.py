@@ -264,3 +264,25 @@ def test_placement_is_resolved_per_job_not_per_task():
     assert resolve_placement("auto", 1, {"DTF_JOB_WORKER_GPUS": "0", "DTF_JOB_PS_GPUS": "0"}) == "dedicated"
     assert resolve_placement("auto", 0, {"DTF_JOB_WORKER_GPUS": "0"}) == "colocated"
     assert resolve_placement("dedicated", 1, envs[1]) == "dedicated"
+
+
+def test_miopen_setup_restricts_solver_families(tmp_path, monkeypatch):
+    """a shape missing from the shipped MIOpen caches must not cost a 36 s JIT stall.  The
+    non-implicit-GEMM solver families (the ones that compile HIP / OpenCL at run time) are switched off unless the
+    user exported a value or asks for MIOpen's defaults."""
+    from distributed_tensorflow_amd.utils import miopen
+
+    for k in miopen._NON_IGEMM + ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR", "DTF_MIOPEN_ALL_SOLVERS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setenv("MIOPEN_DEBUG_CONV_WINOGRAD", "1")          # an explicit user choice wins
+    db = miopen.setup()
+    assert db and os.path.isdir(db) and any(f.endswith(".txt") for f in os.listdir(db))
+    assert os.environ["MIOPEN_DEBUG_CONV_DIRECT"] == "0" and os.environ["MIOPEN_DEBUG_CONV_GEMM"] == "0"
+    assert os.environ["MIOPEN_DEBUG_CONV_FFT"] == "0" and os.environ["MIOPEN_DEBUG_CONV_WINOGRAD"] == "1"
+    cache = os.environ["MIOPEN_CUSTOM_CACHE_DIR"]
+    assert any(f.endswith(".ukdb") for f in os.listdir(cache))
+    for k in miopen._NON_IGEMM:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DTF_MIOPEN_ALL_SOLVERS", "1")
+    assert miopen.restrict_solvers() is False and "MIOPEN_DEBUG_CONV_DIRECT" not in os.environ

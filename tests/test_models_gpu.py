@@ -258,3 +258,28 @@ def test_batchnorm_statistics_with_mean_far_from_zero(dev, mean, std):
     assert float(err) < 0.04, float(err)
     torch.testing.assert_close(rm.double(), 0.1 * mu, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(rv.double(), 0.9 + 0.1 * var * (N * H * W) / (N * H * W - 1), rtol=2e-3, atol=1e-4)
+
+
+def test_untuned_shape_reaches_first_step_quickly(tmp_path):
+    """Inception-v3 at a batch size that is in NO shipped database used to need 35-36 s of run-time
+    kernel compilation before step 1 (``profiles/r1_cancel_hung_inception_hbm_reclaim.json``).  With the solver families
+    restricted to implicit GEMM (``utils/miopen.py``) the shipped kernel cache serves it: 5 s measured
+    (``profiles/r2_miopen_cache_miss.txt``).  Runs bench.py in a child process with a private, freshly copied cache."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith("MIOPEN_") and k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = str(tmp_path)
+    p = subprocess.run([sys.executable, "-u", os.path.join(root, "bench.py"), "--model", "inception_v3", "--batch", "24",
+                        "--steps", "2", "--warmup", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stderr[-2000:]
+    m = re.search(r"warmup step 1 done at \+([0-9.]+) s", p.stderr)
+    assert m, p.stderr[-2000:]
+    assert float(m.group(1)) < 15.0, "first step of an untuned shape took %s s" % m.group(1)
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["config"]["miopen_shipped_db"] is True and rec["value"] > 0
