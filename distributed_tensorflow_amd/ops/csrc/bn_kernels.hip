@@ -27,6 +27,8 @@
 #define BN_ROWS 32        // rows per block iteration
 #define BN_UNROLL 4
 
+__device__ __forceinline__ int64_t dtf_mask_bytes_dev(int64_t M, int C) { return (int64_t)((C + BN_CT - 1) / BN_CT) * M * 8; }
+
 enum { BN_FWD_STATS = 0, BN_BWD_RELU_X = 1, BN_BWD_PLAIN = 2, BN_BWD_RELU_MASK = 3 };
 
 // Row-chunk schedule.  rows_per_block > 0: block b owns the contiguous rows [b * rows_per_block, ...) (round 1).
@@ -213,6 +215,64 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
             float s = red[0][stat][cc] + red[1][stat][cc] + red[2][stat][cc] + red[3][stat][cc];
             partial[((int64_t)bx * 2 + stat) * C + c] = s;
         }
+    }
+}
+
+// Forward statistics, flat variant: the tensor is read as ONE contiguous stream, 4 KB (256 lanes x 16 B) per block
+// iteration, U iterations in flight, grid-strided -- the access shape that reads a cold tensor at 6.3-6.9 TB/s
+// (scripts/ubench/read_only.hip, profiles/r2_straggler_kernels.txt), where the [rows x 64-channel tile] mapping above
+// touches one 128-B line per row and tile and stays at 3.3-3.6 TB/s.  Requires a dense tensor (ldx == C) and
+// 2048 % C == 0: every 16-byte vector a lane loads then holds the SAME 8 channels, (8 * tid) % C.
+// The fold over the 2048 / C lanes that share a channel and the partial layout ([block][2][C]) match
+// bn_reduce_kernel, so the finalize kernels are shared; summation order is fixed by the code (bitwise reproducible).
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void bn_stats_flat_kernel(const unsigned short* __restrict__ x,
+                                                            float* __restrict__ partial, int64_t nvec, int C) {
+    const int tid = threadIdx.x;
+    const int c0 = (tid * 8) & (C - 1);
+    float mu[8], s1[8], s2[8];
+    ld8bf(x + c0, mu);                      // shifted accumulation against row 0 (see bn_reduce_kernel)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x);
+    const int64_t step = (int64_t)gridDim.x * (256 * U);
+    for (int64_t v = (int64_t)blockIdx.x * (256 * U) + tid; v < nvec; v += step) {
+        u32x4 a[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = v + u * 256 < nvec;
+            if (ok[u]) a[u] = NT ? __builtin_nontemporal_load(xv + DTF_IDX(v + u * 256, nvec, "bn_stats_flat vector")) : xv[v + u * 256];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d0 = __uint_as_float(a[u][k] << 16) - mu[2 * k];
+                const float d1 = __uint_as_float(a[u][k] & 0xffff0000u) - mu[2 * k + 1];
+                s1[2 * k] += d0;
+                s2[2 * k] = fmaf(d0, d0, s2[2 * k]);
+                s1[2 * k + 1] += d1;
+                s2[2 * k + 1] = fmaf(d1, d1, s2[2 * k + 1]);
+            }
+        }
+    }
+    __shared__ float red[2][2048];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        // [k][tid] layout: conflict-free stores; position p = 8 * tid + k of the 2048-element block row is channel p % C
+        red[0][k * 256 + tid] = s1[k];
+        red[1][k * 256 + tid] = s2[k];
+    }
+    __syncthreads();
+    const int groups = 2048 / C;            // lanes sharing a channel: tid = c / 8 + g * (C / 8)
+    for (int idx = tid; idx < 2 * C; idx += 256) {
+        const int stat = idx >= C, c = idx - stat * C;
+        const int k = c & 7, t0 = c >> 3;
+        float sum = 0.f;
+        for (int g = 0; g < groups; ++g) sum += red[stat][k * 256 + t0 + g * (C >> 3)];
+        partial[((int64_t)blockIdx.x * 2 + stat) * C + c] = sum;
     }
 }
 
@@ -428,6 +488,198 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const unsigned short*
             st8bf(dx + row * lddx + c0, xv[u]);
             if (RES) st8bf(dres + row * C + c0, dv[u]);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Flat variants of the elementwise passes (C <= 2048).  One block per U contiguous pieces of ~4 KB, no loop: the
+// shape in which a cold x (+ residual) -> y pass measured 6.05-6.37 TB/s against 4.8-5.0 for the [rows x 64-channel
+// tile] kernels above (scripts/ubench/stream_variants.hip, profiles/r2_bn_schedule_ab.txt).  The ReLU bit-mask
+// layout is unchanged.
+// ---------------------------------------------------------------------------
+template <bool NT> __device__ __forceinline__ u32x4 ldv(const u32x4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ void stv(u32x4* p, u32x4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void cvt8(u32x4 r, float (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(r[k] << 16); v[2 * k + 1] = __uint_as_float(r[k] & 0xffff0000u); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+    u32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+    return r;
+}
+
+// Lane mapping: cv = C / 8 vectors per row, rpi = 256 / cv rows per block iteration; lane tid owns the channels
+// 8 * (tid % cv) of row tid / cv (lanes >= rpi * cv idle: none when C is a power of two, < 10 % otherwise).  For a
+// dense tensor a block iteration is ONE contiguous piece of rpi * C * 2 bytes; row strides (channel slices of a wider
+// NHWC tensor, read or written in place) only change the address arithmetic.
+template <bool RELU, bool RES, int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void bn_fwd_apply_flat_kernel(const unsigned short* __restrict__ x,
+                                                                const unsigned short* __restrict__ res,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                unsigned short* __restrict__ y,
+                                                                unsigned char* __restrict__ mask, int64_t M, int C,
+                                                                int cv, int rpi, int64_t ldy, int64_t ldx) {
+    const int tr = threadIdx.x / cv, c0 = (threadIdx.x - tr * cv) * 8;
+    if (tr >= rpi) return;
+    const int64_t row0 = (int64_t)blockIdx.x * (U * rpi) + tr;
+    u32x4 a[U], r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + u * rpi;
+        if (row < M) {
+            a[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(x + row * ldx + c0));
+            if (RES) r[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(res + row * C + c0));
+        }
+    }
+    float sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + u * rpi;
+        if (row >= M) continue;
+        float f[8], g[8];
+        cvt8(a[u], f);
+        if (RES) cvt8(r[u], g);
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float o = fmaf(f[k], sc[k], sh[k]);
+            if (RES) o += g[k];
+            if (RELU) {
+                m |= (o > 0.f ? 1u : 0u) << k;
+                o = fmaxf(o, 0.f);
+            }
+            f[k] = o;
+        }
+        stv<NTS>(reinterpret_cast<u32x4*>(y + row * ldy + c0), pack8(f));
+        if (RELU && RES)
+            mask[DTF_IDX(((int64_t)(c0 >> 6) * M + row) * 8 + ((c0 & 63) >> 3), dtf_mask_bytes_dev(M, C), "bn flat mask")] = (unsigned char)m;
+    }
+}
+
+template <int MODE, bool RES, int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void bn_bwd_apply_flat_kernel(const unsigned short* __restrict__ dy,
+                                                                const unsigned short* __restrict__ x,
+                                                                const unsigned char* __restrict__ mask,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ coef,
+                                                                unsigned short* __restrict__ dx,
+                                                                unsigned short* __restrict__ dres, int64_t M, int C,
+                                                                int cv, int rpi, int64_t lddy, int64_t ldx, int64_t lddx) {
+    const int tr = threadIdx.x / cv, c0 = (threadIdx.x - tr * cv) * 8;
+    if (tr >= rpi) return;
+    const int64_t row0 = (int64_t)blockIdx.x * (U * rpi) + tr;
+    u32x4 a[U], d[U];
+    unsigned mb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + u * rpi;
+        if (row < M) {
+            d[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(dy + row * lddy + c0));
+            a[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(x + row * ldx + c0));
+            if (MODE == BN_BWD_RELU_MASK) mb[u] = mask[((int64_t)(c0 >> 6) * M + row) * 8 + ((c0 & 63) >> 3)];
+        }
+    }
+    float k1[8], k2[8], k3[8], sc[8], sh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        k1[k] = coef[c0 + k]; k2[k] = coef[C + c0 + k]; k3[k] = coef[2 * C + c0 + k];
+        sc[k] = 0.f; sh[k] = 0.f;
+    }
+    if (MODE == BN_BWD_RELU_X) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + u * rpi;
+        if (row >= M) continue;
+        float xf[8], df[8];
+        cvt8(a[u], xf);
+        cvt8(d[u], df);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float g = df[k];
+            if (MODE == BN_BWD_RELU_X) g = fmaf(xf[k], sc[k], sh[k]) > 0.f ? g : 0.f;
+            if (MODE == BN_BWD_RELU_MASK) g = ((mb[u] >> k) & 1u) ? g : 0.f;
+            df[k] = g;
+            xf[k] = fmaf(k1[k], g, fmaf(k2[k], xf[k], k3[k]));
+        }
+        stv<NTS>(reinterpret_cast<u32x4*>(dx + row * lddx + c0), pack8(xf));
+        if (RES) stv<NTS>(reinterpret_cast<u32x4*>(dres + row * C + c0), pack8(df));
+    }
+}
+
+// Backward reduction, flat variant (see bn_stats_flat_kernel): s1 = sum dy', s2 = sum dy' * (x - mean) per channel,
+// dy' = dy under the ReLU mask.  Dense tensors, C a power of two; partial layout [block][2][C].
+template <int MODE, int U, bool NT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_flat_kernel(const unsigned short* __restrict__ x,
+                                                                 const unsigned short* __restrict__ dy,
+                                                                 const unsigned char* __restrict__ mask,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 float* __restrict__ partial, int64_t M, int C, int log2c) {
+    const int tid = threadIdx.x;
+    const int64_t nvec = (M * C) >> 3;
+    const int c0 = (tid * 8) & (C - 1);
+    float mu[8], sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = mean[c0 + k]; sc[k] = 0.f; sh[k] = 0.f; }
+    if (MODE == BN_BWD_RELU_X) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = scale[c0 + k]; sh[k] = shift[c0 + k]; }
+    }
+    const u32x4* xv = reinterpret_cast<const u32x4*>(x);
+    const u32x4* dv = reinterpret_cast<const u32x4*>(dy);
+    const unsigned char* mbase = mask + (int64_t)(c0 >> 6) * M * 8 + ((c0 & 63) >> 3);
+    const int64_t step = (int64_t)gridDim.x * (256 * U);
+    for (int64_t v = (int64_t)blockIdx.x * (256 * U) + tid; v < nvec; v += step) {
+        u32x4 a[U], d[U];
+        unsigned mb[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t w = v + u * 256;
+            ok[u] = w < nvec;
+            if (ok[u]) {
+                d[u] = ldv<NT>(dv + w);
+                a[u] = ldv<NT>(xv + w);
+                if (MODE == BN_BWD_RELU_MASK) mb[u] = mbase[((w << 3) >> log2c) * 8];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            float xf[8], df[8];
+            cvt8(a[u], xf);
+            cvt8(d[u], df);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float g = df[k];
+                if (MODE == BN_BWD_RELU_X) g = fmaf(xf[k], sc[k], sh[k]) > 0.f ? g : 0.f;
+                if (MODE == BN_BWD_RELU_MASK) g = ((mb[u] >> k) & 1u) ? g : 0.f;
+                s1[k] += g;
+                s2[k] = fmaf(g, xf[k] - mu[k], s2[k]);
+            }
+        }
+    }
+    __shared__ float red[2][2048];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[0][k * 256 + tid] = s1[k]; red[1][k * 256 + tid] = s2[k]; }
+    __syncthreads();
+    const int groups = 2048 / C;
+    for (int idx = tid; idx < 2 * C; idx += 256) {
+        const int stat = idx >= C, c = idx - stat * C;
+        const int k = c & 7, t0 = c >> 3;
+        float sum = 0.f;
+        for (int g = 0; g < groups; ++g) sum += red[stat][k * 256 + t0 + g * (C >> 3)];
+        partial[((int64_t)blockIdx.x * 2 + stat) * C + c] = sum;
     }
 }
 
@@ -652,6 +904,40 @@ static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, i
     *ctiles = ct;
 }
 
+// Forward statistics pass: flat stream kernel where the layout allows it (see bn_stats_flat_kernel), the
+// [rows x channel tile] kernel otherwise.  Returns the number of partial rows written.
+static int bn_flat_stats = -1;     // DTF_BN_FLAT_STATS: 0 off, 1 on, 2 (default) on with non-temporal loads
+static inline int bn_flat_grid(int64_t M, int C) {
+    if (C < 8 || C > 2048 || (2048 % C) != 0) return 0;
+    int64_t g = 262144 / C;                 // partial rows: <= 2 MB of fp32 partials
+    if (g > 1024) g = 1024;
+    if (g < 256) g = 256;
+    const int64_t nvec = M * C / 8;
+    const int64_t most = (nvec + 256 * 8 - 1) / (256 * 8);
+    if (g > most) g = most;
+    return (int)g;
+}
+static int launch_fwd_stats(const unsigned short* x, float* partial, int64_t M, int C, int64_t ldx, hipStream_t stream) {
+    if (bn_flat_stats < 0) {
+        const char* e = getenv("DTF_BN_FLAT_STATS");
+        bn_flat_stats = e ? atoi(e) : 2;
+    }
+    const int g = (bn_flat_stats && ldx == C) ? bn_flat_grid(M, C) : 0;
+    if (g > 0) {
+        const int64_t nvec = M * C / 8;
+        if (bn_flat_stats == 2)
+            hipLaunchKernelGGL((bn_stats_flat_kernel<8, true>), dim3(g), dim3(256), 0, stream, x, partial, nvec, C);
+        else
+            hipLaunchKernelGGL((bn_stats_flat_kernel<8, false>), dim3(g), dim3(256), 0, stream, x, partial, nvec, C);
+        return g;
+    }
+    int nb, rpb, ct;
+    bn_grid(M, C, &nb, &rpb, &ct);
+    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream, x, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, partial, M, C, rpb, (int64_t)C, ldx);
+    return nb;
+}
+
 static void bn_init_order() {
     if (bn_sweep < 0) {
         const char* e = getenv("DTF_BN_SWEEP");
@@ -668,11 +954,45 @@ void dtf_bn_set_sweep(int on) { bn_sweep = on ? 1 : 0; }
 int64_t dtf_bn_partial_floats(int64_t M, int C) {
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
-    return (int64_t)nb * 2 * C;
+    const int flat = bn_flat_grid(M, C);
+    return (int64_t)(nb > flat ? nb : flat) * 2 * C;
 }
+
+void dtf_bn_set_flat_stats(int mode) { bn_flat_stats = mode; }
 
 // bytes of the ReLU bit mask of an [M, C] tensor (BN + residual + ReLU only)
 int64_t dtf_bn_mask_bytes(int64_t M, int C) { return (int64_t)((C + BN_CT - 1) / BN_CT) * M * 8; }
+
+// DTF_BN_FLAT_APPLY selects the flat elementwise kernels for dense power-of-two-channel tensors:
+//   0 off, 1 U=1, 2 U=2, 5 U=4 (plain loads/stores), 3 U=4 non-temporal loads+stores, 4 U=4 nt stores, 6 U=4 nt loads,
+//   7 U=2 nt loads, 8 U=8 nt loads, 9 U=2 nt loads+stores
+static int bn_flat_apply = -1;
+static inline int bn_flat_apply_mode(int64_t M, int C) {
+    if (bn_flat_apply < 0) {
+        const char* e = getenv("DTF_BN_FLAT_APPLY");
+        bn_flat_apply = e ? atoi(e) : 9;
+    }
+    if (!bn_flat_apply || C < 8 || C > 2048) return 0;
+    return bn_flat_apply;
+}
+static inline int ilog2(int c) { int l = 0; while ((1 << l) < c) ++l; return l; }
+#define BN_FLAT_DISPATCH(MODE_, LAUNCH)                      \
+    switch (MODE_) {                                         \
+        case 1: LAUNCH(1, false, false); break;              \
+        case 2: LAUNCH(2, false, false); break;              \
+        case 3: LAUNCH(4, true, true); break;                \
+        case 4: LAUNCH(4, false, true); break;               \
+        case 6: LAUNCH(4, true, false); break;               \
+        case 7: LAUNCH(2, true, false); break;               \
+        case 8: LAUNCH(8, true, false); break;               \
+        case 9: LAUNCH(2, true, true); break;                \
+        default: LAUNCH(4, false, false); break;             \
+    }
+static inline unsigned bn_flat_blocks(int64_t M, int C, int mode) {
+    const int U = mode == 1 ? 1 : ((mode == 2 || mode == 7 || mode == 9) ? 2 : (mode == 8 ? 8 : 4));
+    const int64_t rows = (int64_t)U * (256 / (C / 8));
+    return (unsigned)((M + rows - 1) / rows);
+}
 
 static void launch_fwd_apply(const void* x, const void* res, void* y, void* mask, const float* scale,
                              const float* shift, int64_t M, int C, int relu, int64_t ldy, int64_t ldx, hipStream_t stream) {
@@ -681,6 +1001,24 @@ static void launch_fwd_apply(const void* x, const void* res, void* y, void* mask
     const unsigned short *xs = (const unsigned short*)x, *rs = (const unsigned short*)res;
     unsigned short* ys = (unsigned short*)y;
     unsigned char* ms = (unsigned char*)mask;
+    const int flat = bn_flat_apply_mode(M, C);
+    if (flat) {
+        const unsigned fb = bn_flat_blocks(M, C, flat);
+        const int cv = C / 8, rpi = 256 / cv;
+#define FLATF(R, S, U_, NL, NS) hipLaunchKernelGGL((bn_fwd_apply_flat_kernel<R, S, U_, NL, NS>), dim3(fb), dim3(256), 0, stream, xs, rs, scale, shift, ys, ms, M, C, cv, rpi, ldy, ldx)
+#define FL_TT(U_, NL, NS) FLATF(true, true, U_, NL, NS)
+#define FL_TF(U_, NL, NS) FLATF(true, false, U_, NL, NS)
+#define FL_FT(U_, NL, NS) FLATF(false, true, U_, NL, NS)
+#define FL_FF(U_, NL, NS) FLATF(false, false, U_, NL, NS)
+        if (relu) { if (res) { BN_FLAT_DISPATCH(flat, FL_TT) } else { BN_FLAT_DISPATCH(flat, FL_TF) } }
+        else { if (res) { BN_FLAT_DISPATCH(flat, FL_FT) } else { BN_FLAT_DISPATCH(flat, FL_FF) } }
+#undef FL_TT
+#undef FL_TF
+#undef FL_FT
+#undef FL_FF
+#undef FLATF
+        return;
+    }
 #define FWD(R, S) hipLaunchKernelGGL((bn_fwd_apply_kernel<R, S>), dim3(nb, ct), dim3(256), 0, stream, xs, rs, scale, shift, ys, ms, M, C, rpb, ldy, ldx)
     if (relu) { if (res) FWD(true, true); else FWD(true, false); }
     else { if (res) FWD(false, true); else FWD(false, false); }
@@ -705,10 +1043,7 @@ int dtf_bn_fwd_train(const void* x, const void* res, void* y, void* mask, const 
     if (ldx == 0) ldx = C;
     if (ldy < C || (ldy & 7) || ldx < C || (ldx & 7)) return -24;
     if (relu && res && !mask) return -22;
-    int nb, rpb, ct;
-    bn_grid(M, C, &nb, &rpb, &ct);
-    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream,
-                       (const unsigned short*)x, nullptr, nullptr, nullptr, nullptr, nullptr, partial, M, C, rpb, (int64_t)C, ldx);
+    const int nb = launch_fwd_stats((const unsigned short*)x, partial, M, C, ldx, stream);
     const float inv_count = 1.0f / (float)M;
     const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
     const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
@@ -732,10 +1067,7 @@ int dtf_bn_stats_train(const void* x, const void* gamma, const void* beta, int p
     DTF_CLEAR_ERRORS();
     bn_init_order();
     if (C % 8 != 0 || M <= 0) return -20;
-    int nb, rpb, ct;
-    bn_grid(M, C, &nb, &rpb, &ct);
-    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream, (const unsigned short*)x, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, partial, M, C, rpb, (int64_t)C, (int64_t)C);
+    const int nb = launch_fwd_stats((const unsigned short*)x, partial, M, C, (int64_t)C, stream);
     const float inv_count = 1.0f / (float)M;
     const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
     const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
@@ -812,20 +1144,61 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
     bn_grid(M, C, &nb, &rpb, &ct);
     const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x;
     const unsigned char* ms = (const unsigned char*)mask;
+    int nred = nb;
+    // DTF_BN_FLAT_REDUCE: 0 off, 1 flat U=4, 2 flat U=4 non-temporal loads, 3 flat U=2, 4 flat U=2 non-temporal loads
+    static int flat_reduce = -1;
+    if (flat_reduce < 0) { const char* e = getenv("DTF_BN_FLAT_REDUCE"); flat_reduce = e ? atoi(e) : 0; }
+    const int fg = (flat_reduce && lddy == C && ldx == C && !(C & (C - 1))) ? bn_flat_grid(M, C) : 0;
+    if (fg > 0) {
+        const int l2 = ilog2(C);
+        nred = fg;
+#define FRED(MODE, U_, NT_) hipLaunchKernelGGL((bn_bwd_reduce_flat_kernel<MODE, U_, NT_>), dim3(fg), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, l2)
+#define FRED_M(MODE) do { if (flat_reduce == 1) FRED(MODE, 4, false); else if (flat_reduce == 2) FRED(MODE, 4, true); else if (flat_reduce == 3) FRED(MODE, 2, false); else FRED(MODE, 2, true); } while (0)
+        if (relu_mode == BN_BWD_RELU_X) FRED_M(BN_BWD_RELU_X);
+        else if (relu_mode == BN_BWD_RELU_MASK) FRED_M(BN_BWD_RELU_MASK);
+        else FRED_M(BN_BWD_PLAIN);
+#undef FRED_M
+#undef FRED
+    } else {
 #define RED(MODE) hipLaunchKernelGGL((bn_reduce_kernel<MODE, BN_UNROLL>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, rpb, lddy, ldx)
     if (relu_mode == BN_BWD_RELU_X) RED(BN_BWD_RELU_X);
     else if (relu_mode == BN_BWD_RELU_MASK) RED(BN_BWD_RELU_MASK);
     else RED(BN_BWD_PLAIN);
 #undef RED
+    }
     const float inv_count = 1.0f / (float)M;
     const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
     if (param_dtype == DTF_BF16)
-        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nred, C,
                            inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
     else
-        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nb, C,
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nred, C,
                            inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
     unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
+    const int flat = bn_flat_apply_mode(M, C);
+    if (flat) {
+        const unsigned fb = bn_flat_blocks(M, C, flat);
+        const int cv = C / 8, rpi = 256 / cv;
+#define FLATB(MODE, S, U_, NL, NS) hipLaunchKernelGGL((bn_bwd_apply_flat_kernel<MODE, S, U_, NL, NS>), dim3(fb), dim3(256), 0, stream, dys, xs, ms, scale, shift, coef, dxs, drs, M, C, cv, rpi, lddy, ldx, lddx)
+#define FB_XT(U_, NL, NS) FLATB(BN_BWD_RELU_X, true, U_, NL, NS)
+#define FB_XF(U_, NL, NS) FLATB(BN_BWD_RELU_X, false, U_, NL, NS)
+#define FB_MT(U_, NL, NS) FLATB(BN_BWD_RELU_MASK, true, U_, NL, NS)
+#define FB_MF(U_, NL, NS) FLATB(BN_BWD_RELU_MASK, false, U_, NL, NS)
+#define FB_PT(U_, NL, NS) FLATB(BN_BWD_PLAIN, true, U_, NL, NS)
+#define FB_PF(U_, NL, NS) FLATB(BN_BWD_PLAIN, false, U_, NL, NS)
+        if (relu_mode == BN_BWD_RELU_X) { if (dres) { BN_FLAT_DISPATCH(flat, FB_XT) } else { BN_FLAT_DISPATCH(flat, FB_XF) } }
+        else if (relu_mode == BN_BWD_RELU_MASK) { if (dres) { BN_FLAT_DISPATCH(flat, FB_MT) } else { BN_FLAT_DISPATCH(flat, FB_MF) } }
+        else { if (dres) { BN_FLAT_DISPATCH(flat, FB_PT) } else { BN_FLAT_DISPATCH(flat, FB_PF) } }
+#undef FB_XT
+#undef FB_XF
+#undef FB_MT
+#undef FB_MF
+#undef FB_PT
+#undef FB_PF
+#undef FLATB
+        DTF_CHECK_LAUNCH();
+        return 0;
+    }
 #define BWD(MODE, S) hipLaunchKernelGGL((bn_bwd_apply_kernel<MODE, S>), dim3(nb, ct), dim3(256), 0, stream, dys, xs, ms, scale, shift, coef, dxs, drs, M, C, rpb, lddy, ldx, lddx)
     if (relu_mode == BN_BWD_RELU_X) { if (dres) BWD(BN_BWD_RELU_X, true); else BWD(BN_BWD_RELU_X, false); }
     else if (relu_mode == BN_BWD_RELU_MASK) { if (dres) BWD(BN_BWD_RELU_MASK, true); else BWD(BN_BWD_RELU_MASK, false); }
@@ -878,21 +1251,19 @@ int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
     float* pa = partial;
-    float* pb = partial + (int64_t)nb * 2 * C;
+    float* pb = partial + dtf_bn_partial_floats(M, C);
     const unsigned short *xas = (const unsigned short*)xa, *xbs = (const unsigned short*)xb;
-    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream, xas, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, pa, M, C, rpb, (int64_t)C, (int64_t)C);
-    hipLaunchKernelGGL((bn_reduce_kernel<BN_FWD_STATS, 8>), dim3(nb, ct), dim3(256), 0, stream, xbs, nullptr, nullptr, nullptr,
-                       nullptr, nullptr, pb, M, C, rpb, (int64_t)C, (int64_t)C);
+    const int nsa = launch_fwd_stats(xas, pa, M, C, (int64_t)C, stream);
+    const int nsb = launch_fwd_stats(xbs, pb, M, C, (int64_t)C, stream);
     const float inv_count = 1.0f / (float)M;
     const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
     const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
 #define FIN(PDT)                                                                                                              \
     do {                                                                                                                      \
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pa, nb, C, inv_count, unbias,    \
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pa, nsa, C, inv_count, unbias,   \
                            gamma_a, beta_a, rm_a, rv_a, momentum_a, eps_a, stats_a, stats_a + C, stats_a + 2 * C,             \
                            stats_a + 3 * C, xas);                                                                             \
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pb, nb, C, inv_count, unbias,    \
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pb, nsb, C, inv_count, unbias,   \
                            gamma_b, beta_b, rm_b, rv_b, momentum_b, eps_b, stats_b, stats_b + C, stats_b + 2 * C,             \
                            stats_b + 3 * C, xbs);                                                                             \
     } while (0)

