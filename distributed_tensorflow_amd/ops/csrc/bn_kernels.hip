@@ -875,6 +875,101 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(const unsigned short
     }
 }
 
+// flat variants of the dual-BatchNorm elementwise passes (same lane mapping as bn_fwd_apply_flat_kernel; all
+// operands of this node are dense)
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void bn2_fwd_apply_flat_kernel(const unsigned short* __restrict__ xa,
+                                                                 const unsigned short* __restrict__ xb,
+                                                                 const float* __restrict__ scale_a, const float* __restrict__ shift_a,
+                                                                 const float* __restrict__ scale_b, const float* __restrict__ shift_b,
+                                                                 unsigned short* __restrict__ y, unsigned char* __restrict__ mask,
+                                                                 int64_t M, int C, int cv, int rpi) {
+    const int tr = threadIdx.x / cv, c0 = (threadIdx.x - tr * cv) * 8;
+    if (tr >= rpi) return;
+    const int64_t row0 = (int64_t)blockIdx.x * (U * rpi) + tr;
+    u32x4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + u * rpi;
+        if (row < M) {
+            a[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(xa + row * C + c0));
+            b[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(xb + row * C + c0));
+        }
+    }
+    float sa[8], ha[8], sb[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sa[k] = scale_a[c0 + k];
+        sb[k] = scale_b[c0 + k];
+        ha[k] = shift_a[c0 + k] + shift_b[c0 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + u * rpi;
+        if (row >= M) continue;
+        float av[8], bv[8];
+        cvt8(a[u], av);
+        cvt8(b[u], bv);
+        unsigned m = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float o = fmaf(av[k], sa[k], fmaf(bv[k], sb[k], ha[k]));
+            m |= (o > 0.f ? 1u : 0u) << k;
+            av[k] = fmaxf(o, 0.f);
+        }
+        stv<NTS>(reinterpret_cast<u32x4*>(y + row * C + c0), pack8(av));
+        mask[DTF_IDX(((int64_t)(c0 >> 6) * M + row) * 8 + ((c0 & 63) >> 3), dtf_mask_bytes_dev(M, C), "bn2 flat mask")] = (unsigned char)m;
+    }
+}
+
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void bn2_bwd_apply_flat_kernel(const unsigned short* __restrict__ dy,
+                                                                 const unsigned short* __restrict__ xa,
+                                                                 const unsigned short* __restrict__ xb,
+                                                                 const unsigned char* __restrict__ mask,
+                                                                 const float* __restrict__ coef_a, const float* __restrict__ coef_b,
+                                                                 unsigned short* __restrict__ dxa, unsigned short* __restrict__ dxb,
+                                                                 int64_t M, int C, int cv, int rpi) {
+    const int tr = threadIdx.x / cv, c0 = (threadIdx.x - tr * cv) * 8;
+    if (tr >= rpi) return;
+    const int64_t row0 = (int64_t)blockIdx.x * (U * rpi) + tr;
+    u32x4 a[U], b[U], d[U];
+    unsigned mk[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + u * rpi;
+        if (row < M) {
+            d[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(dy + row * C + c0));
+            a[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(xa + row * C + c0));
+            b[u] = ldv<NTL>(reinterpret_cast<const u32x4*>(xb + row * C + c0));
+            mk[u] = mask[((int64_t)(c0 >> 6) * M + row) * 8 + ((c0 & 63) >> 3)];
+        }
+    }
+    float a1[8], a2[8], a3[8], b1[8], b2[8], b3[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a1[k] = coef_a[c0 + k]; a2[k] = coef_a[C + c0 + k]; a3[k] = coef_a[2 * C + c0 + k];
+        b1[k] = coef_b[c0 + k]; b2[k] = coef_b[C + c0 + k]; b3[k] = coef_b[2 * C + c0 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t row = row0 + u * rpi;
+        if (row >= M) continue;
+        float av[8], bv[8], dv[8];
+        cvt8(a[u], av);
+        cvt8(b[u], bv);
+        cvt8(d[u], dv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float g = ((mk[u] >> k) & 1u) ? dv[k] : 0.f;
+            av[k] = fmaf(a1[k], g, fmaf(a2[k], av[k], a3[k]));
+            bv[k] = fmaf(b1[k], g, fmaf(b2[k], bv[k], b3[k]));
+        }
+        stv<NTS>(reinterpret_cast<u32x4*>(dxa + row * C + c0), pack8(av));
+        stv<NTS>(reinterpret_cast<u32x4*>(dxb + row * C + c0), pack8(bv));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1269,6 +1364,13 @@ int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const
     } while (0)
     if (param_dtype == DTF_BF16) FIN(DTF_BF16); else FIN(DTF_F32);
 #undef FIN
+    if (bn_flat_apply_mode(M, C)) {
+        // U = 2, non-temporal loads + stores: the variant that measured best for the single-BN passes
+        const int cv = C / 8, rpi = 256 / cv;
+        const unsigned fb = (unsigned)((M + 2 * rpi - 1) / (2 * rpi));
+        hipLaunchKernelGGL((bn2_fwd_apply_flat_kernel<2, true, true>), dim3(fb), dim3(256), 0, stream, xas, xbs, stats_a + 2 * C,
+                           stats_a + 3 * C, stats_b + 2 * C, stats_b + 3 * C, (unsigned short*)y, (unsigned char*)mask, M, C, cv, rpi);
+    } else
     hipLaunchKernelGGL(bn2_fwd_apply_kernel, dim3(nb, ct), dim3(256), 0, stream, xas, xbs, stats_a + 2 * C, stats_a + 3 * C,
                        stats_b + 2 * C, stats_b + 3 * C, (unsigned short*)y, (unsigned char*)mask, M, C, rpb);
     DTF_CHECK_LAUNCH();
@@ -1303,6 +1405,12 @@ int dtf_bn2_bwd_train(const void* dy, const void* xa, const void* xb, const void
     } while (0)
     if (param_dtype == DTF_BF16) FIN(DTF_BF16); else FIN(DTF_F32);
 #undef FIN
+    if (bn_flat_apply_mode(M, C)) {
+        const int cv = C / 8, rpi = 256 / cv;
+        const unsigned fb = (unsigned)((M + 2 * rpi - 1) / (2 * rpi));
+        hipLaunchKernelGGL((bn2_bwd_apply_flat_kernel<2, true, true>), dim3(fb), dim3(256), 0, stream, dys, xas, xbs,
+                           (const unsigned char*)mask, coef_a, coef_b, (unsigned short*)dxa, (unsigned short*)dxb, M, C, cv, rpi);
+    } else
     hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3(nb, ct), dim3(256), 0, stream, dys, xas, xbs, (const unsigned char*)mask, coef_a,
                        coef_b, (unsigned short*)dxa, (unsigned short*)dxb, M, C, rpb);
     DTF_CHECK_LAUNCH();
