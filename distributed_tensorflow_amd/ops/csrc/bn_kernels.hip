@@ -221,57 +221,65 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
 // Forward statistics, flat variant: the tensor is read as ONE contiguous stream, 4 KB (256 lanes x 16 B) per block
 // iteration, U iterations in flight, grid-strided -- the access shape that reads a cold tensor at 6.3-6.9 TB/s
 // (scripts/ubench/read_only.hip, profiles/r2_straggler_kernels.txt), where the [rows x 64-channel tile] mapping above
-// touches one 128-B line per row and tile and stays at 3.3-3.6 TB/s.  Requires a dense tensor (ldx == C) and
-// 2048 % C == 0: every 16-byte vector a lane loads then holds the SAME 8 channels, (8 * tid) % C.
-// The fold over the 2048 / C lanes that share a channel and the partial layout ([block][2][C]) match
+// touches one 128-B line per row and tile and stays at 3.3-3.6 TB/s.  Lane mapping as in the flat apply kernels
+// below: cv = C / 8 vectors per row, rpi = 256 / cv rows per block iteration, lane tid owns channels 8 * (tid % cv)
+// of row tid / cv (C <= 2048; for a dense tensor an iteration is one contiguous piece, a row stride only changes
+// the addresses).  The fold over the rpi lanes that share a channel and the partial layout ([block][2][C]) match
 // bn_reduce_kernel, so the finalize kernels are shared; summation order is fixed by the code (bitwise reproducible).
 template <int U, bool NT>
 __global__ __launch_bounds__(256) void bn_stats_flat_kernel(const unsigned short* __restrict__ x,
-                                                            float* __restrict__ partial, int64_t nvec, int C) {
+                                                            float* __restrict__ partial, int64_t M, int C, int cv,
+                                                            int rpi, int64_t ldx) {
     const int tid = threadIdx.x;
-    const int c0 = (tid * 8) & (C - 1);
+    const int tr = tid / cv, tc = tid - tr * cv, c0 = tc * 8;
+    const bool active = tr < rpi;
     float mu[8], s1[8], s2[8];
-    ld8bf(x + c0, mu);                      // shifted accumulation against row 0 (see bn_reduce_kernel)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
-    const u32x4* xv = reinterpret_cast<const u32x4*>(x);
-    const int64_t step = (int64_t)gridDim.x * (256 * U);
-    for (int64_t v = (int64_t)blockIdx.x * (256 * U) + tid; v < nvec; v += step) {
-        u32x4 a[U];
-        bool ok[U];
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = 0.f; }
+    if (active) {
+        ld8bf(x + c0, mu);                  // shifted accumulation against row 0 (see bn_reduce_kernel)
+        const int64_t step = (int64_t)gridDim.x * (U * rpi);
+        for (int64_t r = (int64_t)blockIdx.x * (U * rpi) + tr; r < M; r += step) {
+            u32x4 a[U];
+            bool ok[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            ok[u] = v + u * 256 < nvec;
-            if (ok[u]) a[u] = NT ? __builtin_nontemporal_load(xv + DTF_IDX(v + u * 256, nvec, "bn_stats_flat vector")) : xv[v + u * 256];
-        }
+            for (int u = 0; u < U; ++u) {
+                const int64_t row = r + (int64_t)u * rpi;
+                ok[u] = row < M;
+                if (ok[u]) {
+                    const u32x4* p = reinterpret_cast<const u32x4*>(x + DTF_IDX(row, M, "bn_stats_flat row") * ldx + c0);
+                    a[u] = NT ? __builtin_nontemporal_load(p) : *p;
+                }
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!ok[u]) continue;
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float d0 = __uint_as_float(a[u][k] << 16) - mu[2 * k];
-                const float d1 = __uint_as_float(a[u][k] & 0xffff0000u) - mu[2 * k + 1];
-                s1[2 * k] += d0;
-                s2[2 * k] = fmaf(d0, d0, s2[2 * k]);
-                s1[2 * k + 1] += d1;
-                s2[2 * k + 1] = fmaf(d1, d1, s2[2 * k + 1]);
+                for (int k = 0; k < 4; ++k) {
+                    const float d0 = __uint_as_float(a[u][k] << 16) - mu[2 * k];
+                    const float d1 = __uint_as_float(a[u][k] & 0xffff0000u) - mu[2 * k + 1];
+                    s1[2 * k] += d0;
+                    s2[2 * k] = fmaf(d0, d0, s2[2 * k]);
+                    s1[2 * k + 1] += d1;
+                    s2[2 * k + 1] = fmaf(d1, d1, s2[2 * k + 1]);
+                }
             }
         }
     }
     __shared__ float red[2][2048];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        // [k][tid] layout: conflict-free stores; position p = 8 * tid + k of the 2048-element block row is channel p % C
+        // [k][tid] layout: conflict-free stores
         red[0][k * 256 + tid] = s1[k];
         red[1][k * 256 + tid] = s2[k];
     }
     __syncthreads();
-    const int groups = 2048 / C;            // lanes sharing a channel: tid = c / 8 + g * (C / 8)
+    // fold the rpi row lanes that share a channel vector, in fixed order
     for (int idx = tid; idx < 2 * C; idx += 256) {
         const int stat = idx >= C, c = idx - stat * C;
         const int k = c & 7, t0 = c >> 3;
         float sum = 0.f;
-        for (int g = 0; g < groups; ++g) sum += red[stat][k * 256 + t0 + g * (C >> 3)];
+        for (int g = 0; g < rpi; ++g) sum += red[stat][k * 256 + t0 + g * cv];
         partial[((int64_t)blockIdx.x * 2 + stat) * C + c] = sum;
     }
 }
@@ -1001,29 +1009,30 @@ static inline void bn_grid(int64_t M, int C, int* nblk_x, int* rows_per_block, i
 
 // Forward statistics pass: flat stream kernel where the layout allows it (see bn_stats_flat_kernel), the
 // [rows x channel tile] kernel otherwise.  Returns the number of partial rows written.
-static int bn_flat_stats = -1;     // DTF_BN_FLAT_STATS: 0 off, 1 on, 2 (default) on with non-temporal loads
+static int bn_flat_stats = -1;     // DTF_BN_FLAT_STATS: 0 off, 1 (default) on, 2 on with non-temporal loads (better alone, worse
+                                   // once the apply passes are flat too: the apply re-reads x out of the Infinity Cache)
 static inline int bn_flat_grid(int64_t M, int C) {
-    if (C < 8 || C > 2048 || (2048 % C) != 0) return 0;
+    if (C < 8 || C > 2048 || (C & 7)) return 0;
     int64_t g = 262144 / C;                 // partial rows: <= 2 MB of fp32 partials
     if (g > 1024) g = 1024;
     if (g < 256) g = 256;
-    const int64_t nvec = M * C / 8;
-    const int64_t most = (nvec + 256 * 8 - 1) / (256 * 8);
+    const int64_t rows = 8 * (256 / (C / 8));       // rows per block iteration x U
+    const int64_t most = (M + rows - 1) / rows;
     if (g > most) g = most;
     return (int)g;
 }
 static int launch_fwd_stats(const unsigned short* x, float* partial, int64_t M, int C, int64_t ldx, hipStream_t stream) {
     if (bn_flat_stats < 0) {
         const char* e = getenv("DTF_BN_FLAT_STATS");
-        bn_flat_stats = e ? atoi(e) : 2;
+        bn_flat_stats = e ? atoi(e) : 1;
     }
-    const int g = (bn_flat_stats && ldx == C) ? bn_flat_grid(M, C) : 0;
+    const int g = bn_flat_stats ? bn_flat_grid(M, C) : 0;
     if (g > 0) {
-        const int64_t nvec = M * C / 8;
+        const int cv = C / 8, rpi = 256 / cv;
         if (bn_flat_stats == 2)
-            hipLaunchKernelGGL((bn_stats_flat_kernel<8, true>), dim3(g), dim3(256), 0, stream, x, partial, nvec, C);
+            hipLaunchKernelGGL((bn_stats_flat_kernel<8, true>), dim3(g), dim3(256), 0, stream, x, partial, M, C, cv, rpi, ldx);
         else
-            hipLaunchKernelGGL((bn_stats_flat_kernel<8, false>), dim3(g), dim3(256), 0, stream, x, partial, nvec, C);
+            hipLaunchKernelGGL((bn_stats_flat_kernel<8, false>), dim3(g), dim3(256), 0, stream, x, partial, M, C, cv, rpi, ldx);
         return g;
     }
     int nb, rpb, ct;

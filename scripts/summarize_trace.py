@@ -45,7 +45,7 @@ def main(path, total_steps=7):
             break
         a, b = idx[-1 - k], idx[-1]
         n = b - a
-        if a + 1 - n >= 0 and names[a + 1:b + 1] == names[a + 1 - n:a + 1]:
+        if n >= 40 and a + 1 - n >= 0 and names[a + 1:b + 1] == names[a + 1 - n:a + 1]:
             per_step = k
             break
     if not per_step:
