@@ -2,6 +2,7 @@
 // Wave = 64 lanes; every memory-bound kernel moves 16 B per lane per access.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #define DTF_WAVE 64
@@ -114,6 +115,23 @@ static inline int dtf_stream_grid(int64_t work_items, int block) {
     int64_t b = (work_items + block - 1) / block;
     if (b < 1) b = 1;
     if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+// Elementwise passes without a per-block result (K1, K2, casts): one block per `block` work items, no cap -- every
+// lane runs its loop body once.  Measured on the shard-apply kernels against the 2048-block grid-strided shape
+// (scripts/ps_apply_bench.py, profiles/r2_straggler_kernels.txt): Adam 4.86 -> 5.46 TB/s on 110 M elements,
+// 4.59 -> 5.20 on 25.6 M; SGD-momentum 5.00 -> 5.38.  DTF_APPLY_GRID_CAP restores a cap for A/B runs.
+static inline int dtf_flat_grid(int64_t work_items, int block) {
+    static int64_t cap = 0;
+    if (cap == 0) {
+        const char* e = getenv("DTF_APPLY_GRID_CAP");
+        cap = e ? atoll(e) : (1ll << 30);
+        if (cap < 1) cap = 1ll << 30;
+    }
+    int64_t b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
     return (int)b;
 }
 

@@ -444,6 +444,22 @@ __global__ __launch_bounds__(256) void emb_sgd_atomic_kernel(float* __restrict__
     }
 }
 
+// DTF_EMB_GRID_CAP: blocks of the gather / sparse-apply kernels.  Default: no cap, one loop body per lane -- at HBM
+// scale (180 GB of tables, profiles/r2_straggler_kernels.txt) the gather went 4.09 -> 4.54 TB/s and sort + segment
+// apply 0.998 -> 0.958 ms against the 2048-block grid-strided shape.
+static inline int emb_grid(int64_t items) {
+    static int64_t cap = 0;
+    if (cap == 0) {
+        const char* e = getenv("DTF_EMB_GRID_CAP");
+        cap = e ? atoll(e) : (1ll << 30);
+        if (cap < 1) cap = 1ll << 30;
+    }
+    int64_t b = (items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
 extern "C" {
 
 int dtf_embedding_gather(const void* table, int table_dtype, const int64_t* idx, void* out, int out_dtype,
@@ -452,7 +468,7 @@ int dtf_embedding_gather(const void* table, int table_dtype, const int64_t* idx,
     if (nbags <= 0) return 0;
     const bool vec = (D % 8 == 0) && ((((uintptr_t)table) | ((uintptr_t)out)) & 15) == 0;
     const int64_t items = vec ? nbags * (D / 8) : nbags * D;
-    const int grid = dtf_stream_grid(items, 256);
+    const int grid = emb_grid(items);
 #define CALL(T, O)                                                                                              \
     do {                                                                                                        \
         if (vec) hipLaunchKernelGGL((embedding_gather_kernel<T, O>), dim3(grid), dim3(256), 0, stream, table,   \
@@ -483,7 +499,7 @@ int dtf_embedding_sparse_apply(void* table, int table_dtype, float* acc, const v
     const int dv = (D + 7) / 8;
     if (opt == EMB_OPT_ROWWISE_ADAGRAD && (64 % dv) != 0) return -31;
     if ((D % 8 == 0) && (((uintptr_t)table | (uintptr_t)grad | (uintptr_t)partial | (uintptr_t)acc) & 15)) return -16;
-    const int grid = dtf_stream_grid(n * dv, 256);
+    const int grid = emb_grid(n * dv);
     if (grad_dtype == DTF_BF16)
         hipLaunchKernelGGL((emb_chunk_partial_kernel<DTF_BF16>), dim3(grid), dim3(256), 0, stream, grad, perm,
                            chunk_begin, sorted_ids, partial, n, D, bag);

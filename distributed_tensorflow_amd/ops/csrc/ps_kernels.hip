@@ -4,7 +4,7 @@
 //   K5  multi-tensor bucket pack / unpack   (replaces per-variable RecvTensor/send)
 //   K8  sum-of-squares, cast/scale helpers  (clip_by_global_norm, casts)
 // SURVEY.md 2.4.  All of them are pure HBM streaming kernels: 16 B per lane per
-// access, 8 elements per thread per iteration, <= 2048 blocks grid-striding,
+// access, 8 elements per thread per iteration, one block per 2048 elements (dtf_flat_grid),
 // no LDS, so the occupancy is register-limited only (target: >= 80 % of the
 // ~6.3 TB/s achievable HBM rate on multi-MB shards).
 //
@@ -314,7 +314,7 @@ int dtf_sgd_momentum_apply(const void* g, int g_dtype, int nsrc, int64_t src_str
     if (nsrc > 1 && (src_stride & 7)) return -17;
     SgdParams a{g, src_stride, nsrc < 1 ? 1 : nsrc, p32, m, p_out, n, hyper, gnorm_sq,
                 lr, momentum, wd, grad_scale, max_norm, nesterov};
-    const int grid = dtf_stream_grid(n >> 3, 256);
+    const int grid = dtf_flat_grid(n >> 3, 256);
 #define CALL(G, O) hipLaunchKernelGGL((sgd_momentum_apply_kernel<G, O>), dim3(grid), dim3(256), 0, stream, a)
     DISPATCH2(g_dtype, out_dtype, CALL);
 #undef CALL
@@ -332,7 +332,7 @@ int dtf_adam_apply(const void* g, int g_dtype, int nsrc, int64_t src_stride, flo
     if (nsrc > 1 && (src_stride & 7)) return -17;
     AdamParams a{g, src_stride, nsrc < 1 ? 1 : nsrc, p32, m, v, p_out, n, hyper, gnorm_sq,
                  lr, beta1, beta2, eps, wd, grad_scale, max_norm, step, adamw, bias_correction};
-    const int grid = dtf_stream_grid(n >> 3, 256);
+    const int grid = dtf_flat_grid(n >> 3, 256);
 #define CALL(G, O) hipLaunchKernelGGL((adam_apply_kernel<G, O>), dim3(grid), dim3(256), 0, stream, a)
     DISPATCH2(g_dtype, out_dtype, CALL);
 #undef CALL
@@ -398,7 +398,7 @@ int dtf_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype, int
     DTF_CLEAR_ERRORS();
     if (n <= 0) return 0;
     if (!aligned16(src) || !aligned16(dst)) return -16;
-    const int grid = dtf_stream_grid(n >> 3, 256);
+    const int grid = dtf_flat_grid(n >> 3, 256);
 #define CALL(S, D) hipLaunchKernelGGL((cast_scale_kernel<S, D>), dim3(grid), dim3(256), 0, stream, src, dst, n, scale)
     DISPATCH2(src_dtype, dst_dtype, CALL);
 #undef CALL
