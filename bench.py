@@ -72,6 +72,9 @@ def main():
     from distributed_tensorflow_amd.utils import miopen as miopen_cache
 
     miopen_db = miopen_cache.setup()      # shipped find-db + kernel cache (offline-tuned convs)
+    from distributed_tensorflow_amd.utils import gemm_tuning
+
+    gemm_db = gemm_tuning.setup()          # shipped hipBLASLt / rocBLAS solution choices (read-only, no run-time tuning)
     import torch
     import torch.distributed as dist
 
@@ -226,7 +229,7 @@ def main():
                        "pull": "all_gather" if ps.family == "scatter" else "broadcast", "staleness": ps.staleness,
                        "wire_dtype": str(ps.wire_dtype).replace("torch.", ""),
                        "update_mode": a.update_mode, "optimizer": opt.kind, "bucket_mb": a.bucket_mb,
-                       "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db),
+                       "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db), "gemm_shipped_db": bool(gemm_db),
                        "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),
                        "host_enqueue_ms_per_step": round(t_probe * 1e3, 3),
                        "host_loop_ms_per_step": round(t_host / a.steps * 1e3, 3),

@@ -148,6 +148,9 @@ def main(argv=None):
     from ..utils import miopen as miopen_cache
 
     miopen_cache.setup()
+    from ..utils import gemm_tuning
+
+    gemm_tuning.setup()       # shipped hipBLASLt / rocBLAS solution choices (read-only, no run-time tuning)
     from ..train.trainer import run_task
 
     rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,

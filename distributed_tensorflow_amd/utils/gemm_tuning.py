@@ -1,0 +1,47 @@
+"""Ship-with-the-tree GEMM solution selection for the plain (library) GEMMs.
+
+The 1x1-convolution data gradients of the conv nets, BERT's QKV / dX projections and the classifier heads run through
+hipBLASLt / rocBLAS (``torch.matmul``).  Their default heuristics are not the fastest solution for several of these
+shapes; PyTorch's TunableOp can time every solution per shape and record the winner.  That tuning is paid once,
+offline (``scripts/gpu_tunableop.sh``, 35-50 s per model on MI355X); the winners live in
+``distributed_tensorflow_amd/gemm_db/gfx950_tunableop.csv`` and :func:`setup` makes every task READ them (tuning
+itself stays off: a shape that is not in the file takes the library default, nothing is timed at run time).
+Measured (``profiles/r2_tunableop.txt``): ResNet-50 +1.0 %, BERT-base +1.4 %, Inception-v3 +-0.
+
+The file starts with validator lines (PyTorch / HIP / hipBLASLt / rocBLAS versions, GPU architecture): TunableOp
+ignores the whole file when they do not match the running stack, so a newer ROCm degrades to the defaults.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import tempfile
+
+_SRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gemm_db", "gfx950_tunableop.csv"))
+_MAX_DEVICES = 16
+
+
+def setup():
+    """Call before the first GEMM.  Idempotent; any PYTORCH_TUNABLEOP_* variable the user exported wins;
+    ``DTF_GEMM_TUNING=0`` switches it off."""
+    if os.environ.get("DTF_GEMM_TUNING", "1") == "0" or not os.path.isfile(_SRC):
+        return None
+    if any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
+        return os.environ.get("PYTORCH_TUNABLEOP_FILENAME")
+    base = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "dtf_gemm_%d" % os.getuid())
+    try:
+        os.makedirs(base, exist_ok=True)
+        # TunableOp inserts the device ordinal in front of the extension: one copy per ordinal a rank may use
+        for d in range(_MAX_DEVICES):
+            dst = os.path.join(base, "gemm%d.csv" % d)
+            if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(_SRC):
+                tmp = dst + ".tmp.%d" % os.getpid()
+                shutil.copyfile(_SRC, tmp)
+                os.replace(tmp, dst)
+    except OSError:
+        return None
+    os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
+    os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
+    os.environ["PYTORCH_TUNABLEOP_VERBOSE"] = "0"
+    os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(base, "gemm.csv")
+    return os.environ["PYTORCH_TUNABLEOP_FILENAME"]

@@ -286,3 +286,28 @@ def test_miopen_setup_restricts_solver_families(tmp_path, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("DTF_MIOPEN_ALL_SOLVERS", "1")
     assert miopen.restrict_solvers() is False and "MIOPEN_DEBUG_CONV_DIRECT" not in os.environ
+
+
+def test_gemm_tuning_setup_is_read_only_and_respects_the_user(tmp_path, monkeypatch):
+    from distributed_tensorflow_amd.utils import gemm_tuning
+
+    for k in list(os.environ):
+        if k.startswith("PYTORCH_TUNABLEOP_") or k == "DTF_GEMM_TUNING":
+            monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    f = gemm_tuning.setup()
+    assert f and os.environ["PYTORCH_TUNABLEOP_ENABLED"] == "1" and os.environ["PYTORCH_TUNABLEOP_TUNING"] == "0"
+    # one copy per device ordinal (TunableOp inserts the ordinal before the extension), validators first
+    d = os.path.dirname(f)
+    assert all(os.path.isfile(os.path.join(d, "gemm%d.csv" % i)) for i in range(8))
+    lines = open(os.path.join(d, "gemm3.csv")).read().splitlines()
+    assert lines[0].startswith("Validator,") and any(l.startswith("GemmTunableOp_BFloat16") for l in lines)
+    # a user who drives TunableOp himself is left alone; DTF_GEMM_TUNING=0 switches the feature off
+    monkeypatch.setenv("PYTORCH_TUNABLEOP_TUNING", "1")
+    monkeypatch.setenv("PYTORCH_TUNABLEOP_FILENAME", "mine.csv")
+    assert gemm_tuning.setup() == "mine.csv" and os.environ["PYTORCH_TUNABLEOP_TUNING"] == "1"
+    for k in list(os.environ):
+        if k.startswith("PYTORCH_TUNABLEOP_"):
+            monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("DTF_GEMM_TUNING", "0")
+    assert gemm_tuning.setup() is None and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ
