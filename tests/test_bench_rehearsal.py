@@ -36,7 +36,7 @@ def test_bench_contract_at_n_ranks(world):
     assert out["config"]["parallelism"] == "dp%d+ps-shard%d" % (world, world)
     assert out["config"]["wire_dtype"] == "bfloat16"
     assert out["value"] > 0 and abs(out["value"] - 2 * world * 2 / (out["ms_per_step"] * 2 / 1e3)) < 0.05 * out["value"]
-    assert out["vs_baseline"] == pytest.approx(out["value"] / {2: 422.0, 4: 852.0, 8: 1734.0}[world], rel=1e-2)
+    assert out["vs_baseline"] == pytest.approx(out["value"] / {2: 422.0, 4: 852.0, 8: 1734.0}[world], rel=1e-2, abs=6e-4)   # rounded to 3 decimals
 
 
 @pytest.mark.parametrize("extra", [("--push", "all_to_all"), ("--num-ps", "1"),
