@@ -645,7 +645,49 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 static int force_nj = 0;         // 3 | 4 pins the 256p tile width (DTF_GEMM_NJ)
 static int force_tile = 0;       // 128 | 256 pins the tile variant (DTF_GEMM_TILE or dtf_gemm_set_tile; A/B runs)
 
+// y = act(z) on a dense bf16 [n] stream: the activation pass behind a LIBRARY GEMM whose epilogue added the bias and
+// wrote the pre-activation z (kept for the backward).  With per-shape tuned hipBLASLt solutions the pair
+// addmm + this pass beats the fused K6 epilogue on BERT's FFN1 shape (131 + ~70 us vs 252 us,
+// scripts/k6_epilogue_bench.py): K6's K = 768 tiles are epilogue-bound, see docs/STATUS.md.
+// One block per two 4 KB pieces, non-temporal loads (z is not read again before the backward).
+__global__ __launch_bounds__(256) void act_fwd_kernel(const unsigned short* __restrict__ z, unsigned short* __restrict__ y,
+                                                      int64_t nvec, int act) {
+    const int64_t v0 = (int64_t)blockIdx.x * 512 + threadIdx.x;
+    const u32x4* zv = reinterpret_cast<const u32x4*>(z);
+    u32x4* yv = reinterpret_cast<u32x4*>(y);
+    u32x4 a[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (v0 + u * 256 < nvec) a[u] = __builtin_nontemporal_load(zv + v0 + u * 256);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (v0 + u * 256 >= nvec) continue;
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float lo = __uint_as_float(a[u][k] << 16), hi = __uint_as_float(a[u][k] & 0xffff0000u);
+            if (act == ACT_RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            else if (act == ACT_GELU) { lo = gelu_erf(lo); hi = gelu_erf(hi); }
+            else if (act == ACT_GELU_TANH) { lo = gelu_tanh_fwd(lo); hi = gelu_tanh_fwd(hi); }
+            o[k] = pack_bf16x2(lo, hi);
+        }
+        yv[v0 + u * 256] = o;
+    }
+}
+
 extern "C" {
+
+// y = act(z), n % 8 == 0, 16-byte aligned
+int dtf_act_fwd(const void* z, void* y, int64_t n, int act, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (n <= 0) return 0;
+    if ((n & 7) || ((((uintptr_t)z) | ((uintptr_t)y)) & 15)) return -16;
+    const int64_t nvec = n >> 3;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((nvec + 511) / 512)), dim3(256), 0, stream, (const unsigned short*)z,
+                       (unsigned short*)y, nvec, act);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
 
 void dtf_gemm_set_tile(int t) { force_tile = t; }
 void dtf_gemm_set_nj(int nj) { force_nj = nj; }

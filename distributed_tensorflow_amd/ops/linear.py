@@ -29,6 +29,7 @@ def _lib():
     if not _declared:
         P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
         hip.declare("dtf_gemm_bias_act", [P, P, P, I, P, P, P, I, I, I, I, P])
+        hip.declare("dtf_act_fwd", [P, P, L, I, P])
         hip.declare("dtf_act_bwd_partial_floats", [L, I], L)
         hip.declare("dtf_act_bwd_bias", [P, P, P, P, I, P, L, I, I, P])
         hip.declare("dtf_gemm_tn_workspace", [I, I, I], L)
@@ -84,6 +85,17 @@ _tn_ws = {}
 _TN_DISABLED = _os.environ.get("DTF_GEMM_TN", "1") == "0"        # A/B switch
 _TN_FUSE_BIAS = _os.environ.get("DTF_TN_FUSE_BIAS", "1") != "0"  # A/B switch
 _PLAIN_LIB = _os.environ.get("DTF_LINEAR_PLAIN_LIB", "1") != "0"  # A/B switch: bias-only forward GEMMs through the library
+# A/B switch: bias + GELU forward as library GEMM (bias epilogue, writes the pre-activation) + one activation pass
+# instead of the fused K6 epilogue; wins where K6's tiles are epilogue-bound (small K, wide N: BERT's FFN1)
+_ACT_LIB = _os.environ.get("DTF_LINEAR_ACT_LIB", "1") != "0"
+
+
+def act_forward(z, act):
+    """``act(z)`` for a contiguous bf16 tensor (kernel ``act_fwd_kernel``)."""
+    y = torch.empty_like(z)
+    rc = _lib().dtf_act_fwd(hip.ptr(z), hip.ptr(y), z.numel(), ACT[act], hip.stream())
+    hip.check(rc, "dtf_act_fwd")
+    return y
 
 
 def gemm_tn_eligible(a, b):
@@ -133,6 +145,10 @@ class _FusedLinear(torch.autograd.Function):
             # nothing to fuse but the bias, which the GEMM library's own epilogue adds: 113 vs 136 us on BERT's
             # QKV projection (scripts/k6_epilogue_bench.py)
             y, pre = torch.addmm(bias, x2, weight.t()), None
+        elif (_ACT_LIB and act in _GELUS and r2 is None and bias is not None and bias.dtype == x2.dtype
+              and weight.shape[0] % 8 == 0 and weight.shape[0] >= 2 * weight.shape[1] and x2.shape[0] >= 4096):
+            pre = torch.addmm(bias, x2, weight.t())
+            y = act_forward(pre, act)
         else:
             y, pre = gemm_bias_act(x2, weight, bias, act, r2, save_preact=(act in _GELUS))
         z = y if act == "relu" else pre      # relu: mask = y > 0 (fused_linear keeps relu+residual unfused)

@@ -2,7 +2,10 @@
 """K6 epilogue cost: plain vs bias vs bias+residual on BERT's N = 768 shapes."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_tensorflow_amd.utils import gemm_tuning
+gemm_tuning.setup()
 import torch
+import torch.nn.functional as F
 from distributed_tensorflow_amd.ops import linear as lin
 
 dev = torch.device("cuda")
@@ -32,4 +35,8 @@ for M, N, K in [(32768, 768, 768), (32768, 768, 3072), (32768, 2304, 768), (3276
     row["bias_res"] = round(timeit(lambda: lin.gemm_bias_act(x, w, b, "none", r)), 1)
     row["bias_gelu_tanh_preact"] = round(timeit(lambda: lin.gemm_bias_act(x, w, b, "gelu_tanh", None, save_preact=True)), 1)
     row["torch_addmm"] = round(timeit(lambda: torch.addmm(b, x, w.t())), 1)
+    row["torch_addmm_residual_beta1"] = round(timeit(lambda: torch.addmm(r, x, w.t())), 1)
+    y = torch.addmm(b, x, w.t())
+    row["torch_gelu_pass"] = round(timeit(lambda: F.gelu(y, approximate="tanh")), 1)
+    row["torch_add_pass"] = round(timeit(lambda: y + r), 1)
     print(json.dumps(row), flush=True)

@@ -2,6 +2,7 @@
 references of the same op (SURVEY 4.1 'Kernel numerics').  Needs an MI355X."""
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -1212,3 +1213,42 @@ def test_dense_embedding_gradient(dev, V, H, n, dtype):
     w3 = w.clone().requires_grad_()
     emb.dense_embedding(ids, w3).backward(dy)
     assert torch.equal(w3.grad, w1.grad)
+
+
+@pytest.mark.parametrize("act", ["gelu", "gelu_tanh", "relu"])
+def test_act_forward_pass_matches_reference(dev, act):
+    from distributed_tensorflow_amd.ops import linear as lin
+
+    torch.manual_seed(0)
+    z = (torch.randn(1000, 776, device=dev) * 2).to(torch.bfloat16)
+    y = lin.act_forward(z, act)
+    zf = z.float()
+    ref = {"gelu": F.gelu(zf), "gelu_tanh": F.gelu(zf, approximate="tanh"), "relu": F.relu(zf)}[act]
+    torch.testing.assert_close(y.float(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_fused_linear_gelu_library_path_matches_k6_path(dev, monkeypatch):
+    """FFN1-shaped layer (wide N, small K): library GEMM + activation pass against the fused K6 epilogue and fp32."""
+    from distributed_tensorflow_amd.ops import linear as lin
+
+    torch.manual_seed(0)
+    M, K, N = 4096, 256, 1024
+    x0 = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w0 = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    b0 = torch.randn(N, device=dev).to(torch.bfloat16)
+    dy = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    outs = []
+    for lib_path in (True, False):
+        monkeypatch.setattr(lin, "_ACT_LIB", lib_path)
+        x, w, b = (t.clone().requires_grad_() for t in (x0, w0, b0))
+        y = lin.fused_linear(x, w, b, act="gelu_tanh")
+        y.backward(dy)
+        outs.append((y.detach().float(), x.grad.float(), w.grad.float(), b.grad.float()))
+    xr, wr, br = (t.float().requires_grad_() for t in (x0, w0, b0))
+    yr = F.gelu(xr @ wr.t() + br, approximate="tanh")
+    yr.backward(dy.float())
+    for got in outs:
+        torch.testing.assert_close(got[0], yr.detach(), rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(got[1], xr.grad, rtol=3e-2, atol=3e-2 * float(xr.grad.abs().max()))
+        torch.testing.assert_close(got[2], wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max()))
+        torch.testing.assert_close(got[3], br.grad, rtol=3e-2, atol=3e-2 * float(br.grad.abs().max()))
