@@ -21,7 +21,7 @@ from ..ops import attention
 from ..ops.layernorm import FusedLayerNorm
 from ..ops.cross_entropy import cross_entropy
 from ..ops.embedding import dense_embedding
-from ..ops.linear import FusedLinear
+from ..ops.linear import FusedLinear, linear_residual_layernorm
 
 
 class _SplitQKV(torch.autograd.Function):
@@ -67,9 +67,9 @@ class Layer(nn.Module):
             q, k, v = _SplitQKV.apply(qkv5)
             ctx = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=drop)
             ctx = ctx.transpose(1, 2).reshape(B, S, H)
-        x = self.attn_ln(self.attn_out(ctx, residual=x))          # residual fused in the GEMM epilogue
+        x = linear_residual_layernorm(ctx, self.attn_out, x, self.attn_ln)      # residual in the GEMM (beta = 1), bias in K10
         h, x = self.inter.forward_fork(x, own_skip_grad=True)
-        return self.out_ln(self.out(h, residual=x))
+        return linear_residual_layernorm(h, self.out, x, self.out_ln)
 
 
 class Bert(nn.Module):

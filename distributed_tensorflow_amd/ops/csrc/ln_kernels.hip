@@ -17,20 +17,26 @@
 #define LN_ROWS_PER_BLOCK 4      // waves per block
 
 template <int NCH, int PDT>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x, const void* __restrict__ gamma,
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __restrict__ x, const void* __restrict__ pre_bias,
+                                                     const void* __restrict__ gamma,
                                                      const void* __restrict__ beta, unsigned short* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int64_t M, int H, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = H >> 3;
     const float inv_h = 1.f / (float)H;
-    float g[NCH][8], b[NCH][8];
+    // pre_bias: a per-column vector added to x before normalising -- the deferred bias of the projection in front of
+    // this LayerNorm (its GEMM ran in the library with beta = 1 on the residual and no bias vector)
+    float g[NCH][8], b[NCH][8], pb[NCH][8];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int ch = lane + 64 * j;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pb[j][k] = 0.f;
         if (ch < nchunk) {
             load8<PDT>(gamma, ch * 8, g[j]);
             load8<PDT>(beta, ch * 8, b[j]);
+            if (pre_bias) load8<PDT>(pre_bias, ch * 8, pb[j]);
         }
     }
     for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK) {
@@ -42,7 +48,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
             if (ch < nchunk) {
                 load8<DTF_BF16>(x, row * H + ch * 8, v[j]);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) s += v[j][k];
+                for (int k = 0; k < 8; ++k) { v[j][k] += pb[j][k]; s += v[j][k]; }
             }
         }
         const float mean = wave_sum(s) * inv_h;
@@ -72,6 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const unsigned short* __res
 // partial[(blockIdx.x * 2 + {0: dgamma, 1: dbeta}) * H + c]
 template <int NCH, int PDT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __restrict__ dy, const unsigned short* __restrict__ x,
+                                                     const void* __restrict__ pre_bias,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const void* __restrict__ gamma, unsigned short* __restrict__ dx,
                                                      float* __restrict__ partial, int64_t M, int H) {
@@ -79,13 +86,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = H >> 3;
     const float inv_h = 1.f / (float)H;
-    float g[NCH][8], dg[NCH][8], db[NCH][8];
+    float g[NCH][8], dg[NCH][8], db[NCH][8], pb[NCH][8];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int ch = lane + 64 * j;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { dg[j][k] = 0.f; db[j][k] = 0.f; g[j][k] = 0.f; }
-        if (ch < nchunk) load8<PDT>(gamma, ch * 8, g[j]);
+        for (int k = 0; k < 8; ++k) { dg[j][k] = 0.f; db[j][k] = 0.f; g[j][k] = 0.f; pb[j][k] = 0.f; }
+        if (ch < nchunk) {
+            load8<PDT>(gamma, ch * 8, g[j]);
+            if (pre_bias) load8<PDT>(pre_bias, ch * 8, pb[j]);
+        }
     }
     for (int64_t row = (int64_t)blockIdx.x * LN_ROWS_PER_BLOCK + wave; row < M; row += (int64_t)gridDim.x * LN_ROWS_PER_BLOCK) {
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const unsigned short* __res
             if (ch < nchunk) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const float xn = (xh[j][k] - mean) * rstd;
+                    const float xn = (xh[j][k] + pb[j][k] - mean) * rstd;
                     const float dyv = d[j][k];
                     dg[j][k] = fmaf(dyv, xn, dg[j][k]);
                     db[j][k] += dyv;
@@ -194,8 +204,8 @@ extern "C" {
 
 int64_t dtf_ln_partial_floats(int64_t M, int H) { return (int64_t)ln_blocks(M) * 2 * H; }
 
-int dtf_ln_fwd(const void* x, const void* gamma, const void* beta, int param_dtype, void* y, float* mean, float* rstd,
-               int64_t M, int H, float eps, hipStream_t stream) {
+int dtf_ln_fwd(const void* x, const void* pre_bias, const void* gamma, const void* beta, int param_dtype, void* y, float* mean,
+               float* rstd, int64_t M, int H, float eps, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (M <= 0) return 0;
     if (H <= 0 || (H & 7) || H > 4096) return -50;
@@ -205,7 +215,7 @@ int dtf_ln_fwd(const void* x, const void* gamma, const void* beta, int param_dty
     const int nb = ln_blocks(M, 16384);
     const unsigned short* xs = (const unsigned short*)x;
     unsigned short* ys = (unsigned short*)y;
-#define LNF(N, P) hipLaunchKernelGGL((ln_fwd_kernel<N, P>), dim3(nb), dim3(256), 0, stream, xs, gamma, beta, ys, mean, rstd, M, H, eps)
+#define LNF(N, P) hipLaunchKernelGGL((ln_fwd_kernel<N, P>), dim3(nb), dim3(256), 0, stream, xs, pre_bias, gamma, beta, ys, mean, rstd, M, H, eps)
 #define LNF_D(N) do { if (param_dtype == DTF_BF16) LNF(N, DTF_BF16); else LNF(N, DTF_F32); } while (0)
     if (H <= 512) LNF_D(1);
     else if (H <= 1024) LNF_D(2);
@@ -217,7 +227,8 @@ int dtf_ln_fwd(const void* x, const void* gamma, const void* beta, int param_dty
     return 0;
 }
 
-int dtf_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const void* gamma, int param_dtype,
+int dtf_ln_bwd(const void* dy, const void* x, const void* pre_bias, const float* mean, const float* rstd, const void* gamma,
+               int param_dtype,
                void* dx, void* dgamma, void* dbeta, float* partial, int64_t M, int H, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     if (M <= 0) return 0;
@@ -232,7 +243,7 @@ int dtf_ln_bwd(const void* dy, const void* x, const float* mean, const float* rs
         hipFuncSetAttribute((const void*)ln_bwd_kernel<8, DTF_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
         attr_set = true;
     }
-#define LNB(N, P) hipLaunchKernelGGL((ln_bwd_kernel<N, P>), dim3(nb), dim3(256), lds, stream, dys, xs, mean, rstd, gamma, dxs, partial, M, H)
+#define LNB(N, P) hipLaunchKernelGGL((ln_bwd_kernel<N, P>), dim3(nb), dim3(256), lds, stream, dys, xs, pre_bias, mean, rstd, gamma, dxs, partial, M, H)
 #define LNB_D(N) do { if (param_dtype == DTF_BF16) LNB(N, DTF_BF16); else LNB(N, DTF_F32); } while (0)
     if (H <= 512) LNB_D(1);
     else if (H <= 1024) LNB_D(2);

@@ -407,6 +407,6 @@ int dtf_cast_scale(const void* src, int src_dtype, void* dst, int dst_dtype, int
 }
 
 int dtf_abi_version() {
-    DTF_CLEAR_ERRORS(); return 2; }
+    DTF_CLEAR_ERRORS(); return 3; }
 
 }  // extern "C"

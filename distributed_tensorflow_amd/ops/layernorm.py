@@ -27,8 +27,8 @@ def _lib():
     if not _declared:
         P, I, L, Fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
         hip.declare("dtf_ln_partial_floats", [L, I], L)
-        hip.declare("dtf_ln_fwd", [P, P, P, I, P, P, P, L, I, Fl, P])
-        hip.declare("dtf_ln_bwd", [P, P, P, P, P, I, P, P, P, P, L, I, P])
+        hip.declare("dtf_ln_fwd", [P, P, P, P, I, P, P, P, L, I, Fl, P])
+        hip.declare("dtf_ln_bwd", [P, P, P, P, P, P, I, P, P, P, P, L, I, P])
         _declared = True
     return lib
 
@@ -43,7 +43,7 @@ def _partial(dev, n):
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, pre_bias=None):
         H = x.shape[-1]
         x2 = x.reshape(-1, H)
         if not x2.is_contiguous():
@@ -51,16 +51,16 @@ class _LayerNorm(torch.autograd.Function):
         M = x2.shape[0]
         y = torch.empty_like(x2)
         stats = torch.empty(2, M, dtype=torch.float32, device=x.device)
-        rc = _lib().dtf_ln_fwd(hip.ptr(x2), hip.ptr(weight), hip.ptr(bias), hip.dt(weight), hip.ptr(y),
+        rc = _lib().dtf_ln_fwd(hip.ptr(x2), hip.ptr(pre_bias), hip.ptr(weight), hip.ptr(bias), hip.dt(weight), hip.ptr(y),
                                stats[0].data_ptr(), stats[1].data_ptr(), M, H, float(eps), hip.stream())
         hip.check(rc, "dtf_ln_fwd")
-        ctx.save_for_backward(x2, weight, stats)
+        ctx.save_for_backward(x2, weight, stats, pre_bias)
         ctx.shape = x.shape
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, weight, stats = ctx.saved_tensors
+        x2, weight, stats, pre_bias = ctx.saved_tensors
         M, H = x2.shape
         dy2 = dy.reshape(M, H)
         if not dy2.is_contiguous():
@@ -69,10 +69,12 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x2)
         dg, db = torch.empty_like(weight), torch.empty_like(weight)
         part = _partial(dy.device, int(lib.dtf_ln_partial_floats(M, H)))
-        rc = lib.dtf_ln_bwd(hip.ptr(dy2), hip.ptr(x2), stats[0].data_ptr(), stats[1].data_ptr(), hip.ptr(weight),
+        rc = lib.dtf_ln_bwd(hip.ptr(dy2), hip.ptr(x2), hip.ptr(pre_bias), stats[0].data_ptr(), stats[1].data_ptr(), hip.ptr(weight),
                             hip.dt(weight), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), hip.ptr(part), M, H, hip.stream())
         hip.check(rc, "dtf_ln_bwd")
-        return dx.view(ctx.shape), dg, db, None
+        # pre_bias gets NO gradient here: it is the deferred bias of the projection in front, whose backward computes
+        # that gradient (the column sum of dx) inside its weight-gradient kernel
+        return dx.view(ctx.shape), dg, db, None, None
 
 
 def kernel_eligible(x, weight, bias):
@@ -86,6 +88,13 @@ def layer_norm(x, weight, bias, eps=1e-5):
     if kernel_eligible(x, weight, bias):
         return _LayerNorm.apply(x, weight, bias, eps)
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+def layer_norm_deferred_bias(x, pre_bias, weight, bias, eps=1e-5):
+    """``layer_norm(x + pre_bias)`` where the GRADIENT of ``pre_bias`` is produced by the caller (see
+    ``ops/linear.py: linear_residual_layernorm``).  Kernel path only -- check :func:`kernel_eligible` first."""
+    assert kernel_eligible(x, weight, bias) and pre_bias.dtype == weight.dtype and pre_bias.numel() == x.shape[-1]
+    return _LayerNorm.apply(x, weight, bias, eps, pre_bias)
 
 
 class FusedLayerNorm(nn.LayerNorm):

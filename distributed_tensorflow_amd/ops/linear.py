@@ -133,7 +133,7 @@ class _FusedLinear(torch.autograd.Function):
     ``FusedLinear`` / K10 LayerNorm chain, whose gradient is a fresh tensor consumed in stream order)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, act, fork=False, own=False):
+    def forward(ctx, x, weight, bias, residual, act, fork=False, own=False, defer_bias=False):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if not x2.is_contiguous():
@@ -141,7 +141,12 @@ class _FusedLinear(torch.autograd.Function):
         r2 = None
         if residual is not None:
             r2 = residual.reshape(-1, weight.shape[0]).contiguous()
-        if _PLAIN_LIB and act in ("none", None) and r2 is None and bias is not None and bias.dtype == x2.dtype:
+        if defer_bias:
+            # X . W^T + residual by the library (beta = 1 on a copy-free out-of-place addmm); the bias vector is added
+            # by the LayerNorm that consumes y (layer_norm_deferred_bias); its gradient still comes from backward()
+            assert r2 is not None and act in ("none", None) and bias is not None
+            y, pre = torch.addmm(r2, x2, weight.t()), None
+        elif _PLAIN_LIB and act in ("none", None) and r2 is None and bias is not None and bias.dtype == x2.dtype:
             # nothing to fuse but the bias, which the GEMM library's own epilogue adds: 113 vs 136 us on BERT's
             # QKV projection (scripts/k6_epilogue_bench.py)
             y, pre = torch.addmm(bias, x2, weight.t()), None
@@ -164,7 +169,7 @@ class _FusedLinear(torch.autograd.Function):
     def backward(ctx, dy, dskip=None):
         x2, weight, z = ctx.saved_tensors
         if dy is None:            # only the pass-through was used
-            return dskip, None, None, None, None, None, None
+            return dskip, None, None, None, None, None, None, None
         N = weight.shape[0]
         dy2 = dy.reshape(-1, N)
         if not dy2.is_contiguous():
@@ -225,7 +230,7 @@ class _FusedLinear(torch.autograd.Function):
                 dw = gemm_tn(dz, x2)                    # K6T: transposed-operand MFMA GEMM, split over M
             else:
                 dw = torch.matmul(dz.t(), x2)
-        return dx, dw, dbias, dres, None, None, None
+        return dx, dw, dbias, dres, None, None, None, None
 
 
 def fused_linear(x, weight, bias=None, act="none", residual=None):
@@ -241,6 +246,34 @@ def fused_linear_fork(x, weight, bias=None, act="none", own_skip_grad=False):
             or _os.environ.get("DTF_LINEAR_FORK", "1") == "0"):
         return fused_linear(x, weight, bias, act), x
     return _FusedLinear.apply(x, weight, bias, None, act, True, own_skip_grad)
+
+
+# A/B switch: projection + residual + LayerNorm with the GEMM in the library (beta = 1) and the bias inside K10
+_RES_LN_LIB = _os.environ.get("DTF_LINEAR_RES_LN_LIB", "1") != "0"
+# measured through the BERT step: +0.5 % with the FFN-output projection (K = 3072) on this path, -0.7 % when the
+# attention-output projection (K = 768, where K6 and the library are on par) takes it too
+_RES_LN_MIN_K = int(_os.environ.get("DTF_LINEAR_RES_LN_MIN_K", "2048"))
+
+
+def linear_residual_layernorm(x, lin, residual, ln):
+    """``ln(lin(x) + residual)`` (BERT's attention-output and FFN-output sublayers).
+
+    Default path: the library GEMM accumulates onto the residual (``addmm``, beta = 1) and the projection's bias
+    vector is added by the K10 LayerNorm kernels on the fly (``pre_bias``), so neither the fused K6 epilogue (whose
+    K = 768 / 3072, N = 768 tiles are epilogue-bound: 187 vs 147 us on BERT's FFN2, ``scripts/k6_epilogue_bench.py``)
+    nor a separate bias pass is needed.  The bias gradient is the column sum of the LayerNorm's input gradient and
+    still rides in the K6T weight-gradient kernel of ``lin``.  Falls back to ``ln(lin(x, residual))``."""
+    from . import layernorm as _ln
+
+    ok = (_RES_LN_LIB and lin.act in ("none", None) and lin.bias is not None and kernel_eligible(x, lin.weight)
+          and lin.in_features >= _RES_LN_MIN_K
+          and len(ln.normalized_shape) == 1 and ln.elementwise_affine
+          and _ln.kernel_eligible(residual, ln.weight, ln.bias) and lin.bias.dtype == ln.weight.dtype
+          and lin.bias.dtype == x.dtype and lin.out_features % 8 == 0)
+    if not ok:
+        return ln(lin(x, residual=residual))
+    y = _FusedLinear.apply(x, lin.weight, lin.bias, residual, lin.act, False, False, True)
+    return _ln.layer_norm_deferred_bias(y, lin.bias, ln.weight, ln.bias, ln.eps)
 
 
 class FusedLinear(nn.Linear):

@@ -1252,3 +1252,41 @@ def test_fused_linear_gelu_library_path_matches_k6_path(dev, monkeypatch):
         torch.testing.assert_close(got[1], xr.grad, rtol=3e-2, atol=3e-2 * float(xr.grad.abs().max()))
         torch.testing.assert_close(got[2], wr.grad, rtol=3e-2, atol=3e-2 * float(wr.grad.abs().max()))
         torch.testing.assert_close(got[3], br.grad, rtol=3e-2, atol=3e-2 * float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("K", [256, 1024])
+def test_linear_residual_layernorm_deferred_bias_matches_fused_path_and_fp32(dev, K, monkeypatch):
+    """ln(lin(x) + residual): library GEMM with beta = 1 + bias inside K10 against the K6-epilogue path and fp32;
+    the projection's bias gradient must arrive exactly once."""
+    from distributed_tensorflow_amd.ops import layernorm as lnmod, linear as lin
+
+    torch.manual_seed(0)
+    M, N = 4096, 256
+    fl = lin.FusedLinear(K, N).to(dev).to(torch.bfloat16)
+    ln = lnmod.FusedLayerNorm(N, eps=1e-12).to(dev).to(torch.bfloat16)
+    with torch.no_grad():
+        fl.bias.uniform_(-1, 1)
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.uniform_(-0.5, 0.5)
+    x0 = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    r0 = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    dy = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    outs = []
+    for lib_path in (True, False):
+        monkeypatch.setattr(lin, "_RES_LN_LIB", lib_path)
+        for p in list(fl.parameters()) + list(ln.parameters()):
+            p.grad = None
+        x, r = x0.clone().requires_grad_(), r0.clone().requires_grad_()
+        y = lin.linear_residual_layernorm(x, fl, r, ln)
+        y.backward(dy)
+        outs.append([t.detach().float().clone() for t in (y, x.grad, r.grad, fl.weight.grad, fl.bias.grad, ln.weight.grad, ln.bias.grad)])
+    xr, rr = x0.float().requires_grad_(), r0.float().requires_grad_()
+    w, b, g, be = (t.detach().float().requires_grad_() for t in (fl.weight, fl.bias, ln.weight, ln.bias))
+    yr = F.layer_norm(xr @ w.t() + b + rr, (N,), g, be, 1e-12)
+    yr.backward(dy.float())
+    refs = [yr.detach(), xr.grad, rr.grad, w.grad, b.grad, g.grad, be.grad]
+    for got in outs:
+        for a, ref in zip(got, refs):
+            torch.testing.assert_close(a, ref, rtol=3e-2, atol=3e-2 * max(1.0, float(ref.abs().max())) * 0.5)
+    # the two paths agree with each other far tighter than with fp32 on the bias gradient (same column sum)
+    torch.testing.assert_close(outs[0][4], outs[1][4], rtol=2e-2, atol=2e-2 * float(refs[4].abs().max()))
