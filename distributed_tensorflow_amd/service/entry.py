@@ -150,7 +150,11 @@ def main(argv=None):
     miopen_cache.setup()
     from ..utils import gemm_tuning
 
-    gemm_tuning.setup()       # shipped hipBLASLt / rocBLAS solution choices (read-only, no run-time tuning)
+    # shipped hipBLASLt / rocBLAS solution choices (read-only, no run-time tuning): +1-1.5 % per step, but 1-1.5 s of
+    # solution look-up before the first step -- on only for jobs long enough to earn that back
+    mode = str(opts.gemm_tuning).lower()
+    if mode in ("on", "1", "true") or (mode == "auto" and opts.steps >= 10000):
+        gemm_tuning.setup()
     from ..train.trainer import run_task
 
     rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,

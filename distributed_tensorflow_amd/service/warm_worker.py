@@ -19,9 +19,6 @@ def preload():
     from ..utils import miopen as miopen_cache
 
     miopen_cache.setup()      # the shipped MIOpen find-db / kernel cache must be in the environment before torch loads
-    from ..utils import gemm_tuning
-
-    gemm_tuning.setup()       # shipped hipBLASLt / rocBLAS solution choices (read-only, no run-time tuning)
     import torch  # noqa: F401
     import torch.distributed  # noqa: F401
 

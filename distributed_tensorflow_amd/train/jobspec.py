@@ -41,6 +41,8 @@ class TrainOptions:
     log_every: int = 10
     fault: str = ""                 # e.g. "exit:worker=1,step=3,code=17" / "hang:worker=0,step=2"
     graph: bool = False             # capture the whole training step in one hipGraph after 3 eager steps
+    gemm_tuning: str = "auto"       # shipped per-shape GEMM choices: on | off | auto (on from 10 000 steps: reading them
+                                    # costs 1-1.5 s before the first step and returns 1-1.5 % per step)
     extra: dict = field(default_factory=dict)
 
 
@@ -64,7 +66,8 @@ def parse_file_field(file_field, cfg=None):
     ``ValueError`` for something that is neither."""
     cfg = cfg or ApiConfig()
     opts = TrainOptions()
-    for key in ("steps", "bucket_mb", "update_mode", "placement", "wire_dtype", "staleness", "ps_shards", "graph"):
+    for key in ("steps", "bucket_mb", "update_mode", "placement", "wire_dtype", "staleness", "ps_shards", "graph",
+                "gemm_tuning"):
         if cfg.has_option("train", key):
             setattr(opts, key, _coerce(key, cfg.get("train", key)))
     f = (file_field or "").strip()

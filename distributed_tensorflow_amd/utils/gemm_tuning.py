@@ -7,6 +7,9 @@ offline (``scripts/gpu_tunableop.sh``, 35-50 s per model on MI355X); the winners
 ``distributed_tensorflow_amd/gemm_db/gfx950_tunableop.csv`` and :func:`setup` makes every task READ them (tuning
 itself stays off: a shape that is not in the file takes the library default, nothing is timed at run time).
 Measured (``profiles/r2_tunableop.txt``): ResNet-50 +1.0 %, BERT-base +1.4 %, Inception-v3 +-0.
+Cost: TunableOp resolves the recorded solution names against the libraries at the first GEMM of each kind, 1.0-1.5 s
+before the first step.  ``bench.py`` (steady-state throughput) always enables it; a job does from 10 000 steps
+(``gemm_tuning=on|off|auto`` in the job's ``file`` options, ``service/entry.py``).
 
 The file starts with validator lines (PyTorch / HIP / hipBLASLt / rocBLAS versions, GPU architecture): TunableOp
 ignores the whole file when they do not match the running stack, so a newer ROCm degrades to the defaults.

@@ -110,7 +110,7 @@ def _linearise(model, beta=3.0):
 
 
 def _compare(name, named_ours, named_ref, loss_ours, loss_ref, loss_rel_tol, control=None, median_tol=0.15,
-             worst_tol=1.0):
+             worst_tol=1.0, worst_filter=None):
     """Loss within ``loss_rel_tol`` (relative) of the fp32 reference.  Gradients: where a precision-matched CONTROL
     exists (the stock modules run in bf16 on the GPU: the error ANY bf16 implementation of this network has against
     fp32), the median and p90 within 1.2x the control's and every well-conditioned parameter within 2x; without a control,
@@ -133,7 +133,11 @@ def _compare(name, named_ours, named_ref, loss_ours, loss_ref, loss_rel_tol, con
         max(loss_rel_tol, 2.5 * abs(control[1] - float(loss_ref)) / abs(float(loss_ref)))
     assert dl < loss_bound, line
     if control is None:
-        assert med < median_tol and worst < worst_tol, line
+        # without a control the per-parameter bound only covers parameters whose gradient is well conditioned by
+        # construction (``worst_filter``): a BatchNorm beta in front of another normalisation has a near-zero true
+        # gradient (a sum of cancelling terms), so its RELATIVE error is noise in any bf16 run (0.5-2 run to run)
+        checked = [e for n, e in errs.items() if worst_filter is None or worst_filter(n)]
+        assert med < median_tol and max(checked) < worst_tol, line
         return med, worst
     cvals = sorted(control[0].values())
     cmed, cp90 = cvals[len(errs) // 2], cvals[int(0.9 * len(cvals))]
@@ -207,7 +211,8 @@ def test_inception_v3_fused_graph_matches_fp32_reference_path(dev):
     loss_ref = inc.loss_fn(ref, (x.float().cpu().contiguous(), y.cpu()))
     loss_ref.backward()
     _compare("inception_v3 fused graph (linearised)", list(ours.named_parameters()), list(ref.named_parameters()),
-             loss.detach(), loss_ref.detach(), loss_rel_tol=3e-3, median_tol=0.2, worst_tol=2.0)
+             loss.detach(), loss_ref.detach(), loss_rel_tol=3e-3, median_tol=0.2, worst_tol=1.0,
+             worst_filter=lambda n: not n.endswith((".bn.bias", ".bn.weight")))
 
 
 def test_resnet50_learns_with_warmup(dev):
