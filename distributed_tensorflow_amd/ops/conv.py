@@ -20,8 +20,42 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-_MM_BWD_DATA_MIN_CIN = 128
-_MM_FWD_MIN_CIN = 1024
+_MM_BWD_DATA_MIN_CIN = int(os.environ.get("DTF_CONV1X1_MM_DGRAD_MIN_CIN", "128"))
+_MM_FWD_MIN_CIN = int(os.environ.get("DTF_CONV1X1_MM_FWD_MIN_CIN", "1024"))
+_MM_FWD_SKIP = {int(c) for c in os.environ.get("DTF_CONV1X1_MM_FWD_SKIP", "").split(",") if c}
+_MM_TUNED = os.environ.get("DTF_CONV1X1_MM_TUNED", "1") != "0"   # A/B switch: 0 = thresholds only
+
+
+def _mm_fwd(x, weight):
+    """Forward product of a 1x1 convolution through the GEMM library?  From ``_MM_FWD_MIN_CIN`` input channels
+    always; below that only when the shipped per-shape solution choices are in use AND hold this exact GEMM
+    (``utils/gemm_tuning.py``): with the library's default heuristics MIOpen wins there, with the recorded solutions
+    the library does (ResNet-50: +3 %)."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cin in _MM_FWD_SKIP:
+        return False
+    if cin >= _MM_FWD_MIN_CIN:
+        return True
+    if _MM_TUNED:
+        from ..utils import gemm_tuning
+
+        shapes = gemm_tuning.tuned_gemm_shapes()
+        return bool(shapes) and ("tn", cout, x.shape[0] * x.shape[2] * x.shape[3], cin) in shapes
+    return False
+
+
+def _mm_dgrad(dy, weight):
+    """Same question for the data gradient ``dx = dy . w``."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cin >= _MM_BWD_DATA_MIN_CIN:
+        return True
+    if _MM_TUNED:
+        from ..utils import gemm_tuning
+
+        shapes = gemm_tuning.tuned_gemm_shapes()
+        return bool(shapes) and ("nn", cin, dy.shape[0] * dy.shape[2] * dy.shape[3], cout) in shapes
+    return False
+
 _TN_WRW_MIN_C = int(os.environ.get("DTF_CONV1X1_TN_MIN_C", "192"))      # K6T weight gradient when min(Cin, Cout) >= this
 _TN_WRW = os.environ.get("DTF_CONV1X1_TN", "1") != "0"
 _ENABLED = os.environ.get("DTF_CONV1X1_MM", "1") != "0"      # A/B switch: 0 = everything through MIOpen
@@ -56,7 +90,7 @@ class _Conv1x1Fn(torch.autograd.Function):
     def forward(ctx, x, weight, mm_fwd=False):
         ctx.save_for_backward(x, weight)
         cout, cin = weight.shape[0], weight.shape[1]
-        if cin >= _MM_FWD_MIN_CIN or mm_fwd:
+        if mm_fwd or _mm_fwd(x, weight):
             y2 = torch.matmul(_rows(x), weight.reshape(cout, cin).t())
             N, _, H, W = x.shape
             return y2.view(N, H, W, cout).permute(0, 3, 1, 2)
@@ -70,7 +104,7 @@ class _Conv1x1Fn(torch.autograd.Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
         need_dx, need_dw = ctx.needs_input_grad[:2]
-        if need_dx and cin >= _MM_BWD_DATA_MIN_CIN:
+        if need_dx and _mm_dgrad(dy, weight):
             N, _, H, W = x.shape
             dx = torch.matmul(_rows(dy), weight.reshape(cout, cin)).view(N, H, W, cin).permute(0, 3, 1, 2)
             need_dx = False
@@ -153,7 +187,7 @@ class _Conv1x1ForkFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.own = bool(own_skip_grad)
         cout, cin = weight.shape[0], weight.shape[1]
-        if cin >= _MM_FWD_MIN_CIN:
+        if _mm_fwd(x, weight):
             N, _, H, W = x.shape
             y = torch.matmul(_rows(x), weight.reshape(cout, cin).t()).view(N, H, W, cout).permute(0, 3, 1, 2)
         else:

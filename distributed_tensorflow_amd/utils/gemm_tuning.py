@@ -24,6 +24,43 @@ _SRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)),
 _MAX_DEVICES = 16
 
 
+_active = False
+
+
+def active():
+    """True when :func:`setup` pointed TunableOp at the shipped file in this process."""
+    return _active and os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1"
+
+
+_fwd_shapes = None
+
+
+def tuned_gemm_shapes():
+    """``{(op, m, n, k)}`` of the shipped file, op in tn / nn / nt, (m, n, k) in the library's column-major naming:
+    for ``y[rows, cout] = x[rows, cin] . w[cout, cin]^T`` that is ``("tn", cout, rows, cin)``, for
+    ``dx[rows, cin] = dy[rows, cout] . w[cout, cin]`` it is ``("nn", cin, rows, cout)``.  Empty when the shipped
+    choices are not in use: ``ops/conv.py`` sends a 1x1 convolution product to the library only when its exact GEMM
+    has a recorded solution (with the default heuristics MIOpen is faster below 1024 input channels: 10 700 vs 10 490
+    images/s; with the recorded solutions the library wins: 10 790 -> 11 150, ``profiles/r2_tunableop.txt``)."""
+    global _fwd_shapes
+    if not active():
+        return frozenset()
+    if _fwd_shapes is None:
+        out = set()
+        try:
+            for line in open(_SRC):
+                parts = line.split(",")
+                if len(parts) < 3 or not parts[0].startswith("GemmTunableOp_BFloat16_"):
+                    continue
+                f = parts[1].split("_")
+                if len(f) >= 4 and f[0] in ("tn", "nn", "nt"):
+                    out.add((f[0], int(f[1]), int(f[2]), int(f[3])))
+        except (OSError, ValueError):
+            pass
+        _fwd_shapes = frozenset(out)
+    return _fwd_shapes
+
+
 def setup():
     """Call before the first GEMM.  Idempotent; any PYTORCH_TUNABLEOP_* variable the user exported wins;
     ``DTF_GEMM_TUNING=0`` switches it off."""
@@ -47,4 +84,6 @@ def setup():
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
     os.environ["PYTORCH_TUNABLEOP_VERBOSE"] = "0"
     os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(base, "gemm.csv")
+    global _active
+    _active = True
     return os.environ["PYTORCH_TUNABLEOP_FILENAME"]

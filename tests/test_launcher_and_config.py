@@ -311,3 +311,33 @@ def test_gemm_tuning_setup_is_read_only_and_respects_the_user(tmp_path, monkeypa
             monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("DTF_GEMM_TUNING", "0")
     assert gemm_tuning.setup() is None and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ
+
+
+def test_tuned_gemm_shapes_drive_the_conv1x1_library_choice(tmp_path, monkeypatch):
+    """A 1x1 convolution product below the channel threshold goes to the GEMM library only when the shipped solution
+    choices are active and hold that exact GEMM."""
+    import torch
+
+    from distributed_tensorflow_amd.ops import conv
+    from distributed_tensorflow_amd.utils import gemm_tuning
+
+    for k in list(os.environ):
+        if k.startswith("PYTORCH_TUNABLEOP_") or k == "DTF_GEMM_TUNING":
+            monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setattr(gemm_tuning, "_active", False)
+    monkeypatch.setattr(gemm_tuning, "_fwd_shapes", None)
+    x = torch.empty(256, 64, 56, 56, device="meta")
+    w_expand = torch.empty(256, 64, 1, 1, device="meta")
+    w_256 = torch.empty(64, 256, 1, 1, device="meta")
+    assert gemm_tuning.tuned_gemm_shapes() == frozenset()
+    assert not conv._mm_fwd(x, w_expand)                                    # default heuristics: MIOpen
+    assert conv._mm_fwd(torch.empty(8, 1024, 14, 14, device="meta"), torch.empty(256, 1024, 1, 1, device="meta"))
+    assert gemm_tuning.setup()
+    shapes = gemm_tuning.tuned_gemm_shapes()
+    assert ("tn", 256, 256 * 56 * 56, 64) in shapes                          # ResNet-50 stage 1 expand, batch 256
+    assert conv._mm_fwd(x, w_expand)
+    assert not conv._mm_fwd(torch.empty(64, 64, 56, 56, device="meta"), w_expand)       # another batch size: not recorded
+    assert not conv._mm_fwd(torch.empty(256, 256, 56, 56, device="meta"), w_256)        # 256 input channels: MIOpen measured faster
+    monkeypatch.setenv("PYTORCH_TUNABLEOP_ENABLED", "0")
+    assert gemm_tuning.tuned_gemm_shapes() == frozenset()
