@@ -44,6 +44,27 @@ def _mm_fwd(x, weight):
     return False
 
 
+# measured: NO -- the library has no good split-K solution for these (740-850 us per GEMM against ~150 us in MIOpen;
+# ResNet-50 11 150 -> 9 070 images/s with all narrow 1x1 weight gradients on it); kept as a switch, off
+_WRW_LIB = os.environ.get("DTF_CONV1X1_WRW_LIB", "0") != "0"
+_WRW_LIB_ALL = os.environ.get("DTF_CONV1X1_WRW_LIB_ALL", "0") == "1"      # tuning runs: every narrow 1x1 weight gradient
+
+
+def _mm_wrw(dy, weight):
+    """Weight gradient ``dw = dy^T . x`` of a NARROW 1x1 convolution (the wide ones are K6T's) through the GEMM library
+    instead of MIOpen?  Only when the shipped solution choices hold this exact GEMM (a split-K / stream-K solution:
+    the reduction runs over all N*H*W pixels, the output is a few thousand elements)."""
+    if _WRW_LIB_ALL:
+        return True
+    if not _MM_TUNED:
+        return False
+    from ..utils import gemm_tuning
+
+    cout, cin = weight.shape[0], weight.shape[1]
+    shapes = gemm_tuning.tuned_gemm_shapes()
+    return bool(shapes) and ("nt", cin, cout, dy.shape[0] * dy.shape[2] * dy.shape[3]) in shapes
+
+
 def _mm_dgrad(dy, weight):
     """Same question for the data gradient ``dx = dy . w``."""
     cout, cin = weight.shape[0], weight.shape[1]
@@ -75,6 +96,8 @@ def _wrw(dy, x, weight):
         dy2, x2 = _rows(dy), _rows(x)
         if gemm_tn_eligible(dy2, x2) and weight.dtype == torch.bfloat16:
             return gemm_tn(dy2, x2).view(cout, cin, 1, 1)
+    if _WRW_LIB and _mm_wrw(dy, weight):
+        return torch.matmul(_rows(dy).t(), _rows(x)).view(cout, cin, 1, 1)
     _, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
                                                    [0, 0], 1, [False, True, False])
     return dw
