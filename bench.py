@@ -78,6 +78,8 @@ def main():
     import torch
     import torch.distributed as dist
 
+    gemm_tuning.after_torch_import()
+
     from distributed_tensorflow_amd.models import get_model_module
     from distributed_tensorflow_amd.ops import hip
     from distributed_tensorflow_amd.parallel.comm import Comm

@@ -176,6 +176,9 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     def mark(what):
         if trace:
             print("[start +%.3f s] %s" % (time.time() - t_start, what), flush=True)
+    from ..utils import gemm_tuning
+
+    gemm_tuning.after_torch_import()      # shipped GEMM choices (if entry.py enabled them) are read-only
     mod = get_model_module(opts.model)
     use_cuda = torch.cuda.is_available() and int(os.environ.get("DTF_NUM_GPUS", "1")) > 0
     device = torch.device("cuda", 0) if use_cuda else torch.device("cpu")

@@ -16,6 +16,7 @@ ignores the whole file when they do not match the running stack, so a newer ROCm
 """
 from __future__ import annotations
 
+import atexit
 import os
 import shutil
 import tempfile
@@ -61,6 +62,18 @@ def tuned_gemm_shapes():
     return _fwd_shapes
 
 
+def after_torch_import():
+    """Read-only use: never write the file back when the process ends."""
+    if not active():
+        return
+    try:
+        import torch.cuda.tunable as tunable
+
+        tunable.write_file_on_exit(False)
+    except Exception:       # older / newer torch without the switch: the private copy makes the write harmless
+        pass
+
+
 def setup():
     """Call before the first GEMM.  Idempotent; any PYTORCH_TUNABLEOP_* variable the user exported wins;
     ``DTF_GEMM_TUNING=0`` switches it off."""
@@ -68,18 +81,17 @@ def setup():
         return None
     if any(k.startswith("PYTORCH_TUNABLEOP_") for k in os.environ):
         return os.environ.get("PYTORCH_TUNABLEOP_FILENAME")
-    base = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "dtf_gemm_%d" % os.getuid())
+    # a PRIVATE copy per process: TunableOp may rewrite its file when the process ends, and tasks of different jobs all
+    # see "device 0" behind HIP_VISIBLE_DEVICES -- a shared file could be rewritten by two of them at once
+    base = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "dtf_gemm_%d" % os.getuid(), str(os.getpid()))
     try:
         os.makedirs(base, exist_ok=True)
         # TunableOp inserts the device ordinal in front of the extension: one copy per ordinal a rank may use
         for d in range(_MAX_DEVICES):
-            dst = os.path.join(base, "gemm%d.csv" % d)
-            if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(_SRC):
-                tmp = dst + ".tmp.%d" % os.getpid()
-                shutil.copyfile(_SRC, tmp)
-                os.replace(tmp, dst)
+            shutil.copyfile(_SRC, os.path.join(base, "gemm%d.csv" % d))
     except OSError:
         return None
+    atexit.register(shutil.rmtree, base, True)
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
     os.environ["PYTORCH_TUNABLEOP_VERBOSE"] = "0"

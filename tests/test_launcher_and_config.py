@@ -299,6 +299,7 @@ def test_gemm_tuning_setup_is_read_only_and_respects_the_user(tmp_path, monkeypa
     assert f and os.environ["PYTORCH_TUNABLEOP_ENABLED"] == "1" and os.environ["PYTORCH_TUNABLEOP_TUNING"] == "0"
     # one copy per device ordinal (TunableOp inserts the ordinal before the extension), validators first
     d = os.path.dirname(f)
+    assert os.path.basename(d) == str(os.getpid())          # private per process
     assert all(os.path.isfile(os.path.join(d, "gemm%d.csv" % i)) for i in range(8))
     lines = open(os.path.join(d, "gemm3.csv")).read().splitlines()
     assert lines[0].startswith("Validator,") and any(l.startswith("GemmTunableOp_BFloat16") for l in lines)
