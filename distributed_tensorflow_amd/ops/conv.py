@@ -23,6 +23,7 @@ import torch.nn.functional as F
 _MM_BWD_DATA_MIN_CIN = int(os.environ.get("DTF_CONV1X1_MM_DGRAD_MIN_CIN", "128"))
 _MM_FWD_MIN_CIN = int(os.environ.get("DTF_CONV1X1_MM_FWD_MIN_CIN", "1024"))
 _MM_FWD_SKIP = {int(c) for c in os.environ.get("DTF_CONV1X1_MM_FWD_SKIP", "").split(",") if c}
+_MM_FWD_SKIP_MAX_COUT = int(os.environ.get("DTF_CONV1X1_MM_FWD_SKIP_MAX_COUT", "1000000"))
 _MM_TUNED = os.environ.get("DTF_CONV1X1_MM_TUNED", "1") != "0"   # A/B switch: 0 = thresholds only
 
 
@@ -32,7 +33,7 @@ def _mm_fwd(x, weight):
     (``utils/gemm_tuning.py``): with the library's default heuristics MIOpen wins there, with the recorded solutions
     the library does (ResNet-50: +3 %)."""
     cout, cin = weight.shape[0], weight.shape[1]
-    if cin in _MM_FWD_SKIP:
+    if cin in _MM_FWD_SKIP and cout <= _MM_FWD_SKIP_MAX_COUT:
         return False
     if cin >= _MM_FWD_MIN_CIN:
         return True
