@@ -107,3 +107,26 @@ def test_mnist_colocated_two_workers(aio):
     assert rd.world == 2 and rd.step == 20
     assert "hid_w/Momentum" in rd.names()
     assert int(rd.replicated()["global_step"]) == 20
+
+
+def test_dedicated_checkpoint_resumes_in_the_colocated_placement(aio):
+    """A checkpoint written by PS TASKS (dedicated placement: one shard per ps task + the chief's index) is the same
+    format as the colocated one: a later job with other task counts and the other placement resumes from it
+    (dedicated tasks themselves do not resume -- docs/STATUS.md)."""
+    a, port, tmp = aio
+    export = str(tmp / "exp")
+    names = _post(port, {"file": "builtin://mnist_mlp?steps=20&batch=64&placement=dedicated&optimizer=momentum&lr=0.05",
+                         "export": export, "detail": {"ps": 1, "worker": 2}})
+    rec = _wait_final(a, parse_task_name(names[0])[0])
+    assert rec["status"] == "succeeded", _logs(a)
+    first = CheckpointReader(export)
+    assert first.step == 20 and first.index.get("placement") == "dedicated" and "hid_w/Momentum" in first.names()
+    w_before = first.read("hid_w").clone()
+    names = _post(port, {"file": "builtin://mnist_mlp?steps=30&batch=64&placement=colocated&optimizer=momentum&lr=0.05&resume=1",
+                         "export": export, "detail": {"ps": 1, "worker": 2}})
+    rec = _wait_final(a, parse_task_name(names[0])[0])
+    assert rec["status"] == "succeeded", _logs(a)
+    assert "resumed from step 20" in _logs(a)
+    second = CheckpointReader(export)
+    assert second.step == 30 and second.world == 2
+    assert (second.read("hid_w") - w_before).abs().max() > 0
