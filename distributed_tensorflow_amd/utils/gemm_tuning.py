@@ -36,6 +36,21 @@ def active():
 _fwd_shapes = None
 
 
+def _validator_ok(key, value):
+    """The two validators that can be checked from Python without touching the libraries (the others are left to
+    TunableOp itself)."""
+    try:
+        import torch
+
+        if key == "PT_VERSION":
+            return torch.__version__.split("+")[0].startswith(value)
+        if key == "GCN_ARCH_NAME" and torch.cuda.is_available():
+            return torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName == value
+    except Exception:
+        return True
+    return True
+
+
 def tuned_gemm_shapes():
     """``{(op, m, n, k)}`` of the shipped file, op in tn / nn / nt, (m, n, k) in the library's column-major naming:
     for ``y[rows, cout] = x[rows, cin] . w[cout, cin]^T`` that is ``("tn", cout, rows, cin)``, for
@@ -50,7 +65,10 @@ def tuned_gemm_shapes():
         out = set()
         try:
             for line in open(_SRC):
-                parts = line.split(",")
+                parts = line.strip().split(",")
+                if parts[0] == "Validator" and len(parts) >= 3 and not _validator_ok(parts[1], parts[2]):
+                    out = set()             # TunableOp will ignore the file: do not route anything by it either
+                    break
                 if len(parts) < 3 or not parts[0].startswith("GemmTunableOp_BFloat16_"):
                     continue
                 f = parts[1].split("_")
