@@ -13,6 +13,7 @@
 // (the framework kernels take 48 us forward and 139 us backward on a [32768, 768] tensor;
 //  the byte counts above are 20 and 30 us at 5 TB/s.)
 #include "dtf_common.h"
+#include <stdlib.h>
 
 #define LN_ROWS_PER_BLOCK 4      // waves per block
 
@@ -209,10 +210,11 @@ int dtf_ln_fwd(const void* x, const void* pre_bias, const void* gamma, const voi
     DTF_CLEAR_ERRORS();
     if (M <= 0) return 0;
     if (H <= 0 || (H & 7) || H > 4096) return -50;
-    // a wave holds ONE row (NCH 16-byte loads per lane) in flight: occupancy has to hide the HBM latency, so the
-    // forward grid covers all 8 block slots of every CU several times over (the backward's grid stays at 1024: its
-    // dgamma / dbeta partial rows scale with it)
-    const int nb = ln_blocks(M, 16384);
+    // grid: 1024 blocks measured best on [32768, 768] (scripts/ln_bench.py: 24.1 us; 2048: 26.6, 4096: 27.1,
+    // 8192+: 30-31 us -- more blocks only re-load gamma / beta more often); DTF_LN_FWD_GRID_CAP for A/B runs
+    static int fwd_cap = 0;
+    if (fwd_cap == 0) { const char* e = getenv("DTF_LN_FWD_GRID_CAP"); fwd_cap = e ? atoi(e) : 1024; if (fwd_cap < 1) fwd_cap = 1024; }
+    const int nb = ln_blocks(M, fwd_cap);
     const unsigned short* xs = (const unsigned short*)x;
     unsigned short* ys = (unsigned short*)y;
 #define LNF(N, P) hipLaunchKernelGGL((ln_fwd_kernel<N, P>), dim3(nb), dim3(256), 0, stream, xs, pre_bias, gamma, beta, ys, mean, rstd, M, H, eps)
