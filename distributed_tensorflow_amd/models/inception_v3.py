@@ -32,6 +32,9 @@ class ConvBN(nn.Module):
         self.bn = FusedBatchNormAct(o, relu=True, eps=1e-3)
 
     def forward(self, x):
+        if isinstance(self.conv, Conv2dTN):
+            y, st = self.conv.forward_stats(x)       # wide layers: K13 implicit GEMM, BN statistics from its epilogue
+            return self.bn(y, stats=st)
         return self.bn(self.conv(x))
 
     def forward_fork(self, x):

@@ -51,6 +51,12 @@ class Bottleneck(nn.Module):
         else:
             self.shortcut_conv = None
 
+    def _conv2_bn2(self, h):
+        if isinstance(self.conv2, Conv2dTN):
+            c, st = self.conv2.forward_stats(h)      # wide layers: K13 implicit GEMM, BN statistics from its epilogue
+            return self.bn2(c, stats=st)
+        return self.bn2(self.conv2(h))
+
     def forward(self, x):
         sc_stride = self.shortcut_conv.stride[0] if self.shortcut_conv is not None else 1
         if (_SUBSAMPLE and sc_stride > 1 and self.shortcut_conv.kernel_size == (1, 1) and isinstance(self.conv1, Conv1x1)
@@ -59,7 +65,7 @@ class Bottleneck(nn.Module):
             # strided 1x1 shortcut = dense 1x1 GEMM of the subsampled input; its gradient is added on those pixels only
             xs, x = subsample_fork(x, sc_stride)
             s = conv1x1(xs, self.shortcut_conv.weight, mm_fwd=True)
-            y = self.bn2(self.conv2(self.bn1(self.conv1(x))))
+            y = self._conv2_bn2(self.bn1(self.conv1(x)))
             return fused_bn2_add_relu(self.conv3(y), self.bn3, s, self.shortcut_bn)
         if isinstance(self.conv1, Conv1x1):
             # x feeds conv1 and the shortcut: the fork sums their two gradients inside conv1's dX GEMM.
@@ -71,7 +77,7 @@ class Bottleneck(nn.Module):
         if self.shortcut_conv is not None and self.training and x.is_cuda:
             # both BatchNorms, the add and the ReLU of a stage's first block in one K7 node
             s = self.shortcut_conv(x)
-            y = self.bn2(self.conv2(self.bn1(y)))
+            y = self._conv2_bn2(self.bn1(y))
             return fused_bn2_add_relu(self.conv3(y), self.bn3, s, self.shortcut_bn)
         if self.shortcut_conv is None:
             sc = x
@@ -80,8 +86,7 @@ class Bottleneck(nn.Module):
             sc = self.shortcut_bn(s, stats=st)
         else:
             sc = self.shortcut_bn(self.shortcut_conv(x))
-        y = self.bn1(y)
-        y = self.bn2(self.conv2(y))
+        y = self._conv2_bn2(self.bn1(y))
         if isinstance(self.conv3, Conv1x1):
             y, st = self.conv3.forward_stats(y)
             return self.bn3(y, sc, stats=st)

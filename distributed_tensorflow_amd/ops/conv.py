@@ -389,6 +389,78 @@ def conv_wrw(dy, x, weight, stride, padding):
     return dw.permute(0, 3, 1, 2)
 
 
+# ---------------------------------------------------------------------------
+# K13: forward convolution as an implicit GEMM on the K6 LDS-DMA pipeline (csrc/conv_kernels.hip)
+# ---------------------------------------------------------------------------
+_fwd_declared = False
+# "auto": the layers where K13 measured faster than MIOpen's tuned kernel (_k13_profitable); "all": every eligible
+# layer; "0": off.  A/B table: profiles/r2_conv_fwd_k13_vs_miopen.txt
+_CONV_FWD = os.environ.get("DTF_CONV_FWD", "auto")
+# measured at batch 256 (scripts/conv_fwd_bench.py): K13 wins from 160 channels on both sides (ResNet stages 3 / 4: 64 vs 74-82
+# and 89 vs 100 us; Inception's 17x17 1x7 / 7x1: 51-59 vs 59-74 us; its 8x8 blocks: 25-67 vs 30-84 us) and loses on the
+# 64 / 96 / 128-channel layers, whose output tile is too narrow for the 8-wave pipeline (HBM / LDS-bound: MIOpen's)
+_CONV_FWD_MIN_CH = int(os.environ.get("DTF_CONV_FWD_MIN_CH", "160"))
+# BatchNorm statistics of the output in K13's epilogue (+2-4 us per layer) instead of a separate pass over it
+_CONV_FWD_STATS = os.environ.get("DTF_CONV_FWD_STATS", "1") != "0"
+
+
+def conv_fwd_profitable(cin, cout):
+    if _CONV_FWD == "0":
+        return False
+    return _CONV_FWD == "all" or min(cin, cout) >= _CONV_FWD_MIN_CH
+
+
+def _fwd_lib():
+    global _fwd_declared
+    import ctypes
+
+    from . import hip
+
+    lib = hip.lib()
+    if not _fwd_declared:
+        P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        hip.declare("dtf_conv_fwd_stats_blocks", [L, I], L)
+        hip.declare("dtf_conv_fwd_set_tile", [I, I], None)
+        hip.declare("dtf_conv_fwd", [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P])
+        _fwd_declared = True
+    return lib
+
+
+def conv_fwd_eligible(x, weight, stride, padding, dilation=(1, 1), groups=1):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4 and groups == 1
+            and tuple(dilation) == (1, 1) and stride[0] == stride[1] and x.shape[1] % 32 == 0 and weight.shape[0] % 8 == 0
+            and weight.shape[2] * weight.shape[3] <= 32 and x.is_contiguous(memory_format=torch.channels_last)
+            and weight.is_contiguous(memory_format=torch.channels_last))
+
+
+def conv_fwd(x, weight, stride, padding, stats=False):
+    """``conv2d(x, weight, None, stride, padding)`` for NHWC bf16 tensors on K13.  ``stats=True`` -> ``(y, partials)``
+    with the fp32 ``[blocks, 2, Cout]`` column sums / sums of squares of ``y`` from the epilogue (what
+    ``FusedBatchNormAct(..., stats=partials)`` finalizes instead of reading ``y`` once more)."""
+    from . import hip
+
+    lib = _fwd_lib()
+    NB, Cin, H, W = x.shape
+    Cout, _, KH, KW = weight.shape
+    s = int(stride[0])
+    OH = (H + 2 * int(padding[0]) - KH) // s + 1
+    OW = (W + 2 * int(padding[1]) - KW) // s + 1
+    dev = x.device
+    z = _zero_page.get(dev)
+    if z is None:
+        z = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+        _zero_page[dev] = z
+    y = torch.empty((NB, OH, OW, Cout), dtype=torch.bfloat16, device=dev)
+    part = None
+    if stats:
+        part = torch.empty(int(lib.dtf_conv_fwd_stats_blocks(NB * OH * OW, Cout)), 2, Cout, dtype=torch.float32, device=dev)
+    rc = lib.dtf_conv_fwd(hip.ptr(x), hip.ptr(weight), hip.ptr(z), hip.ptr(y), hip.ptr(part) if stats else None, NB, H, W, Cin,
+                          OH, OW, Cout, KH, KW, s, int(padding[0]), int(padding[1]), hip.stream())
+    hip.check(rc, "dtf_conv_fwd")
+    y = y.permute(0, 3, 1, 2)
+    return (y, part) if stats else y
+
+
 # Data gradient of a stride-1 convolution as a FORWARD convolution of dY with the spatially flipped, channel-
 # transposed filter (padding K-1-p).  MIOpen's tuned forward kernels run at 500-830 TFLOP/s on the 3x3 / 1x7 / 7x1
 # shapes of ResNet and Inception, its backward-data kernels at 300-490 (scripts/conv_wrw_bench.py with
@@ -438,7 +510,10 @@ def dgrad_as_forward(dy, weight, padding):
         wt = buf.permute(0, 3, 1, 2)          # [Cin, Cout, KH, KW], channels_last-dense
     else:
         wt = weight.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
-    return F.conv2d(dy, wt, None, 1, (kh - 1 - padding[0], kw - 1 - padding[1]))
+    pad = (kh - 1 - padding[0], kw - 1 - padding[1])
+    if conv_fwd_profitable(cout, cin) and conv_fwd_eligible(dy, wt, (1, 1), pad):
+        return conv_fwd(dy, wt, (1, 1), pad)
+    return F.conv2d(dy, wt, None, 1, pad)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -446,13 +521,22 @@ class _ConvFn(torch.autograd.Function):
     as a forward convolution where that wins, MIOpen's backward kernels otherwise."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding):
+    def forward(ctx, x, weight, stride, padding, stats=False):
+        """``stats=True`` -> ``(y, partials)``: the BatchNorm statistics partials of ``y`` from K13's epilogue (``None``
+        when the layer runs in MIOpen)."""
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, padding)
-        return F.conv2d(x, weight, None, stride, padding)
+        if conv_fwd_profitable(weight.shape[1], weight.shape[0]) and conv_fwd_eligible(x, weight, stride, padding):
+            if stats:
+                y, part = conv_fwd(x, weight, stride, padding, stats=True)
+                ctx.mark_non_differentiable(part)
+                return y, part
+            return conv_fwd(x, weight, stride, padding)
+        y = F.conv2d(x, weight, None, stride, padding)
+        return (y, None) if stats else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart=None):
         x, weight = ctx.saved_tensors
         stride, padding = ctx.geom
         if not dy.is_contiguous(memory_format=torch.channels_last):
@@ -470,16 +554,30 @@ class _ConvFn(torch.autograd.Function):
             dx = dgrad_as_forward(dy, weight, padding)
         if use_tn:
             dw = conv_wrw(dy, x, weight, stride, padding)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class Conv2dTN(nn.Conv2d):
     """``nn.Conv2d`` (bias-free, groups 1) whose backward picks the kernel per product (see :class:`_ConvFn`)."""
 
+    def _own(self, x):
+        """Route through :class:`_ConvFn`?  -> (yes / no, forward on K13)."""
+        if not (self.bias is None and self.groups == 1 and x.is_cuda and x.dtype == torch.bfloat16
+                and isinstance(self.padding, tuple) and self.dilation == (1, 1)):
+            return False, False
+        k13 = (conv_fwd_profitable(self.in_channels, self.out_channels)
+               and conv_fwd_eligible(x, self.weight, self.stride, self.padding))
+        bwd = torch.is_grad_enabled() and ((_CONV_WRW and conv_wrw_profitable(self.weight))
+                                           or _dgrad_as_fwd_ok(x, self.weight, self.stride, self.padding))
+        return k13 or bwd, k13
+
     def forward(self, x):
-        if (self.bias is None and self.groups == 1 and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
-                and isinstance(self.padding, tuple) and self.dilation == (1, 1)
-                and ((_CONV_WRW and conv_wrw_profitable(self.weight))
-                     or _dgrad_as_fwd_ok(x, self.weight, self.stride, self.padding))):
-            return _ConvFn.apply(x, self.weight, self.stride, self.padding)
+        if self._own(x)[0]:
+            return _ConvFn.apply(x, self.weight, self.stride, self.padding, False)
         return super().forward(x)
+
+    def forward_stats(self, x):
+        """-> ``(self(x), stats or None)`` for a following ``FusedBatchNormAct(y, ..., stats=stats)`` in training."""
+        if _CONV_FWD_STATS and self.training and self._own(x)[1]:
+            return _ConvFn.apply(x, self.weight, self.stride, self.padding, True)
+        return self(x), None

@@ -954,9 +954,90 @@ def test_conv_data_gradient_as_forward_convolution(dev, cfg, monkeypatch):
     assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
 
 
-@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (192, 160, 7, 1), (96, 48, 5, 5), (384, 448, 3, 3), (72, 8, 1, 7)])
-def test_filter_flip_transpose_kernel(dev, shape):
+@pytest.mark.parametrize("cfg", [
+    # NB, Cin, H, W, Cout, KH, KW, stride, pad
+    (4, 64, 14, 14, 128, 3, 3, 1, (1, 1)),
+    (3, 128, 15, 13, 256, 3, 3, 2, (1, 1)),
+    (2, 160, 17, 17, 192, 1, 7, 1, (0, 3)),
+    (2, 160, 17, 17, 160, 7, 1, 1, (3, 0)),
+    (2, 64, 12, 12, 128, 5, 5, 1, (2, 2)),
+    (5, 256, 7, 7, 512, 3, 3, 1, (1, 1)),
+    (2, 288, 19, 19, 384, 3, 3, 2, (0, 0)),
+    (9, 256, 14, 14, 256, 3, 3, 1, (1, 1)),
+    (2, 32, 11, 11, 72, 3, 3, 1, (1, 1)),
+    (3, 512, 9, 9, 520, 1, 1, 2, (0, 0)),
+    (1, 32, 5, 5, 8, 3, 3, 1, (2, 2)),
+])
+@pytest.mark.parametrize("tile", [(0, 0), (4, 8), (4, 7), (3, 5), (4, 4), (2, 8), (2, 4)])
+def test_conv_fwd_implicit_gemm_matches_reference(dev, cfg, tile):
+    """K13 (implicit-GEMM forward convolution on the K6 LDS-DMA pipeline) against fp32 conv2d, every tile family, with the
+    BatchNorm statistics epilogue: strides, paddings (incl. wider than 'same'), tap counts, row / column tile edges."""
     from distributed_tensorflow_amd.ops import conv
+
+    NB, Cin, H, W, Cout, KH, KW, stride, pad = cfg
+    torch.manual_seed(0)
+    x = torch.randn(NB, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, KH, KW, device=dev) * (Cin * KH * KW) ** -0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert conv.conv_fwd_eligible(x, w, (stride, stride), pad)
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, pad)
+    lib = conv._fwd_lib()
+    lib.dtf_conv_fwd_set_tile(*tile)
+    try:
+        y, part = conv.conv_fwd(x, w, (stride, stride), pad, stats=True)
+        y0 = conv.conv_fwd(x, w, (stride, stride), pad)
+    finally:
+        lib.dtf_conv_fwd_set_tile(0, 0)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+    assert float((y.float() - ref).norm() / ref.norm()) < 5e-3
+    assert torch.equal(y, y0)                                  # the statistics epilogue does not change the output
+    yf = y.float()
+    torch.testing.assert_close(part[:, 0].sum(0), yf.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(part[:, 1].sum(0), (yf * yf).sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("cfg", [(4, 160, 14, 14, 192, 3, 3, 1, (1, 1)), (3, 256, 15, 13, 256, 3, 3, 2, (1, 1)),
+                                 (2, 192, 17, 17, 160, 1, 7, 1, (0, 3)), (2, 64, 9, 9, 96, 3, 3, 1, (1, 1))])
+def test_conv_module_on_k13_with_bn_statistics(dev, cfg, monkeypatch):
+    """Conv2dTN routed to K13 (forward, data gradient as a forward convolution of dY, BatchNorm fed from the epilogue
+    statistics) against the fp32 composition conv2d -> batch_norm -> relu."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, conv
+
+    NB, Cin, H, W, Cout, KH, KW, stride, pad = cfg
+    monkeypatch.setattr(conv, "_CONV_FWD", "all")
+    torch.manual_seed(0)
+    x = torch.randn(NB, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    m = conv.Conv2dTN(Cin, Cout, (KH, KW), stride=stride, padding=pad, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    bn = bnmod.FusedBatchNormAct(Cout, relu=True).to(dev).to(torch.bfloat16).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x2, w2 = x.float().requires_grad_(), m.weight.detach().float().requires_grad_()
+    g2, b2 = bn.weight.detach().float().requires_grad_(), bn.bias.detach().float().requires_grad_()
+    c2 = torch.nn.functional.conv2d(x2, w2, None, stride, pad)
+    o2 = torch.relu(torch.nn.functional.batch_norm(c2, None, None, g2, b2, True, 0.1, 1e-5))
+    dy = torch.randn_like(o2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    o2.backward(dy.float())
+    x1 = x.clone().requires_grad_()
+    c1, st = m.forward_stats(x1)
+    assert st is not None and "ConvFn" in type(c1.grad_fn).__name__
+    o1 = bn(c1, stats=st)
+    o1.backward(dy)
+    torch.testing.assert_close(o1.float(), o2, rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(bn.running_var, 0.9 + 0.1 * c2.var((0, 2, 3), unbiased=True), rtol=2e-2, atol=1e-3)
+    assert float((x1.grad.float() - x2.grad).norm() / x2.grad.norm()) < 3e-2
+    assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 3e-2
+    assert float((bn.weight.grad.float() - g2.grad).norm() / g2.grad.norm()) < 3e-2
+    # eval mode / no_grad: still K13, no statistics
+    with torch.no_grad():
+        torch.testing.assert_close(m(x).float(), c2.detach(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 3, 3), (192, 160, 7, 1), (96, 48, 5, 5), (384, 448, 3, 3), (72, 8, 1, 7)])
+def test_filter_flip_transpose_kernel(dev, shape, monkeypatch):
+    from distributed_tensorflow_amd.ops import conv
+
+    monkeypatch.setattr(conv, "_CONV_FWD", "0")        # both sides through the same convolution kernel: bitwise
 
     cout, cin, kh, kw = shape
     torch.manual_seed(0)
