@@ -189,20 +189,20 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
             }
         }
     };
-    auto stage = [&](int t) {
+    // piece q of K tile t: the wave's A pieces first (q < NA), then its B pieces
+    auto stage_piece = [&](int t, int q) {
         unsigned char* base = smem + (t & 3) * 32768;
         const int k0 = t * 32;
-#pragma unroll
-        for (int i = 0; i < (NA > NB ? NA : NB); ++i) {
-            if (i < NA) {
-                const unsigned short* src;
-                if constexpr (CONV) src = ((amask[i] >> s_tap) & 1u) ? pa[i] + s_koff : zp;
-                else src = pa[i] + k0;
-                __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(base + (wave * NA + i) * 1024), 16, 0, 0);
-            }
-            if (i < NB)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(pb[i] + k0), (lds_void_t*)(base + 16384 + (wave * NB + i) * 1024), 16, 0, 0);
+        if (q < NA) {
+            const unsigned short* src;
+            if constexpr (CONV) src = ((amask[q] >> s_tap) & 1u) ? pa[q] + s_koff : zp;
+            else src = pa[q] + k0;
+            __builtin_amdgcn_global_load_lds((glb_void_t*)src, (lds_void_t*)(base + (wave * NA + q) * 1024), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(pb[q - NA] + k0), (lds_void_t*)(base + 16384 + (wave * NB + q - NA) * 1024), 16, 0, 0);
         }
+    };
+    auto stage_advance = [&]() {
         if constexpr (CONV) {          // next K tile: 32 channels on; past the last channel tile the next tap IS +32
             s_koff += 32;              // elements on (tap offset = (r cW + s) cC), except at the end of a filter row
             if (++s_cc == cpt) {
@@ -211,6 +211,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
                 if (++s_s == a.cKW) { s_s = 0; s_koff += (a.cW - a.cKW) * a.cC; }
             }
         }
+    };
+    auto stage = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < GL; ++q) stage_piece(t, q);
+        stage_advance();
     };
     auto prologue = [&]() {
         stage(0);
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
             for (int j = 0; j < NJ; ++j)      // operands swapped: D[n][m], 4 consecutive n per lane
                 acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[0], acc[0][j], 0, 0, 0);
             // the restage rides in the MFMA phase: an LDS-DMA piece costs 60-180 issue cycles, which made the
-            // READ phase (12 ds_read_b128 + 4 pieces) twice as long as the 512-cycle MFMA phase it overlaps
+            // READ phase (12 ds_read_b128 + 4 pieces) twice as long as the 512-cycle MFMA phase it overlaps.  All pieces
+            // in ONE block: one piece between every two fragment rows measured 24 % SLOWER (4096^3: 1172 -> 896 TF).
             if (!pair) {
                 if (t + 3 < nk) stage(t + 3);
             } else if ((t & 1) == 0) {
