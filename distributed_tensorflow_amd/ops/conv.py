@@ -396,9 +396,10 @@ _fwd_declared = False
 # "auto": the layers where K13 measured faster than MIOpen's tuned kernel (_k13_profitable); "all": every eligible
 # layer; "0": off.  A/B table: profiles/r2_conv_fwd_k13_vs_miopen.txt
 _CONV_FWD = os.environ.get("DTF_CONV_FWD", "auto")
-# measured at batch 256 (scripts/conv_fwd_bench.py): K13 wins from 160 channels on both sides (ResNet stages 3 / 4: 64 vs 74-82
-# and 89 vs 100 us; Inception's 17x17 1x7 / 7x1: 51-59 vs 59-74 us; its 8x8 blocks: 25-67 vs 30-84 us) and loses on the
-# 64 / 96 / 128-channel layers, whose output tile is too narrow for the 8-wave pipeline (HBM / LDS-bound: MIOpen's)
+# measured at batch 256 (scripts/conv_fwd_bench.py, profiles/r2_conv_fwd_k13_vs_miopen.txt): K13 wins from 160 channels on
+# both sides (ResNet stages 3 / 4: 55-58 vs 79-84 and 64-66 vs 105 us; Inception's 17x17 1x7 / 7x1: 46-55 vs 63-79 us; its
+# 8x8 blocks: 23-58 vs 31-87 us), ties at 128 channels (93 vs 94 us, but saves the statistics pass) and loses on the
+# 64 / 96-channel layers, whose output tile is too narrow for the 8-wave pipeline
 _CONV_FWD_MIN_CH = int(os.environ.get("DTF_CONV_FWD_MIN_CH", "160"))
 # BatchNorm statistics of the output in K13's epilogue (+2-4 us per layer) instead of a separate pass over it
 _CONV_FWD_STATS = os.environ.get("DTF_CONV_FWD_STATS", "1") != "0"

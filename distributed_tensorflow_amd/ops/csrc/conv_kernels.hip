@@ -19,8 +19,8 @@ struct Variant { int nj, mi; double cost; };
 // (NJ, MI) tiles built below with the measured time of ONE round of such tiles over the CUs (us at K = 4608,
 // scripts/conv_fwd_bench.py; only the ratios matter).  Not proportional to the tile area: the pipeline is bound by LDS
 // traffic, i.e. by MI + NJ fragment reads and by the number of LDS-DMA pieces per wave (MI = 4 stages ONE piece of A).
-const Variant kVariants[] = {{4, 8, 132.}, {4, 7, 120.}, {4, 6, 113.}, {4, 5, 108.}, {4, 4, 89.}, {3, 8, 115.}, {3, 7, 109.},
-                             {3, 6, 105.}, {3, 5, 97.5}, {3, 4, 77.}, {2, 8, 99.}, {2, 4, 69.}};
+const Variant kVariants[] = {{4, 8, 90.}, {4, 7, 81.}, {4, 6, 79.}, {4, 5, 77.}, {4, 4, 64.}, {3, 8, 83.}, {3, 7, 77.},
+                             {3, 6, 75.}, {3, 5, 74.}, {3, 4, 59.}, {2, 8, 70.}, {2, 4, 51.5}};
 int force_nj = 0, force_mi = 0;
 int num_cu = 0;
 bool inited = false;
@@ -97,6 +97,7 @@ int dtf_conv_fwd(const void* x, const void* w, const void* zero, void* y, float*
     a.M = (int)M64; a.N = Cout; a.K = KH * KW * Cin; a.act = ACT_NONE;
     a.ntm = (int)((M64 + 32 * mi - 1) / (32 * mi)); a.ntn = (Cout + 64 * nj - 1) / (64 * nj);
     a.stats = stats; a.zero = (const unsigned short*)zero;
+    { static int gm = 0; if (gm <= 0) { const char* e = getenv("DTF_CONV_FWD_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } a.group_m = gm; }
     a.cH = H; a.cW = W; a.cC = Cin; a.cOH = OH; a.cOW = OW; a.cKH = KH; a.cKW = KW; a.cS = stride; a.cPH = ph; a.cPW = pw;
 #define CF_CASE(NJ_, MI_)                                                         \
     if (nj == NJ_ && mi == MI_) {                                                 \

@@ -50,6 +50,7 @@ struct GemmArgs {
     // [N = Cout][cKH][cKW][cC] (K = cKH * cKW * cC), Y the NHWC output [NB, cOH, cOW, N] (M = NB * cOH * cOW)
     const unsigned short* zero;      // >= 64 B of zeros: the source of filter taps that fall into the padding
     int cH, cW, cC, cOH, cOW, cKH, cKW, cS, cPH, cPW;
+    int group_m;                     // tile order: row panels per group (>= 1; 1 = row-major)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -72,8 +73,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 //        wr=1:     | R0 w1 | M0 | R1 w2 | ...     wN = wait for own pieces of tile N, | = s_barrier
 //    Tile N is first read (by wr=0) after the barrier that follows both groups' wN; buffers are restaged
 //    in phase R(t), which for both groups starts after the barrier that ended the last read of tile t-1.
-//  * K > 4096 stages tiles in PAIRS so the two 64-B halves of every 128-B line are requested back to back
-//    (8192^3: 931 -> 1155 TF); smaller K keeps the deeper one-tile-per-step schedule.
+//  * Tile order: groups of 4 row panels x all column panels, row panel fastest, on top of the XCD remap: the ~32
+//    tiles that run on one XCD at a time form a 4 x 8 block and pull 4 + 8 operand panels per K step through its
+//    L2 instead of 1 + 32 (8192^3: 1074 -> 1337 TF together with dropping the earlier "stage K tiles in pairs" mode,
+//    which only papered over that traffic).
 //  * Epilogue straight from the accumulators: the MFMA operands are swapped (D = W.X^T fragment), so a
 //    lane holds 4 CONSECUTIVE output columns of one row -- bias / activation / residual in registers and
 //    8-byte stores (the four j fragments of a wave complete each 128-B line), no LDS round trip and no
@@ -84,6 +87,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // multiple of 32 here (no zero fill with LDS-DMA) -- other K use the 128 kernel.
 // ---------------------------------------------------------------------------
 #define G2_BM 256
+#ifndef G2_RH
+#define G2_RH -1
+#endif
 #define G2_BN 256
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -124,13 +130,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
     constexpr int NB = (NJ + 1) / 2;           // NJ: the last pieces are over-staged rows of the neighbouring tile)
     constexpr int GL = NA + NB;                // LDS-DMA instructions per wave per K tile
     constexpr int BM = 32 * MI;
+    // pieces restaged in the READ phase (the rest in the MFMA phase): all of them when the partner's MFMA phase is
+    // long enough to hide them, one less for the short MFMA phases of the small tiles (measured, G2_RH = 0..4 builds:
+    // 4096^3 1175 / 1175 / 1207 / 1256 / 1276 TF; 256-channel 3x3 convolution 65.4 / 62.8 / 58.3 / 59.1 / 56.2 us;
+    // 160 x 192 tile 61.1 / 57.8 / 56.8 / 55.8 / 61.7 us)
+    constexpr int RH = G2_RH >= 0 ? (G2_RH < GL ? G2_RH : GL) : (MI * NJ >= 24 ? GL : GL - 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int K = a.K;
     const int nk = K / 32;
-    const bool pair = K > 4096;
     const int frow = lane & 15, fq = lane >> 4;
     const int lane_off = frow * 64 + ((fq ^ ((4 - (frow >> 2)) & 3)) << 4);
 
@@ -143,7 +153,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
     if constexpr (CONV) zp = a.zero + ((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) * 8;
     int m0 = 0, n0 = 0;
     auto set_tile = [&](int tile) {        // wave w stages row groups NA w .. of A and NB w .. of B
-        const int tm = tile / a.ntn, tn = tile - tm * a.ntn;
+        // grouped order: group_m row panels x all column panels at a time, row panel fastest -- the ~32 consecutive
+        // tiles that run on one XCD at a time then cover a (group_m x 32 / group_m) block and fetch group_m A panels +
+        // 32 / group_m B panels per K step into its L2 instead of 1 + 32 (row-major order)
+        const int width = a.group_m * a.ntn, g = tile / width, first = g * a.group_m;
+        const int gsz = a.ntm - first < a.group_m ? a.ntm - first : a.group_m;
+        const int in_g = tile - g * width;
+        const int tn = in_g / gsz, tm = first + (in_g - tn * gsz);
         m0 = tm * BM;
         n0 = tn * (64 * NJ);
         if constexpr (CONV) {
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
     auto prologue = [&]() {
         stage(0);
         if (nk > 1) stage(1);
-        if (!pair && nk > 2) stage(2);
+        if (nk > 2) stage(2);
     };
     // tiles that may still be in flight when tile t+1 is needed: staged so far (UPTO) minus (t+1)
 #define G2_WAIT_NEXT(T, UPTO)                                                        \
@@ -260,9 +276,22 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
             for (int j = 0; j < NJ; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(B + j * 1024);
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(A + i * 1024);
+            // RH of the GL pieces of tile t+3 are issued HERE, in the READ phase, where their issue stalls overlap the
+            // partner wave's MFMAs (all GL here made this phase longer than the MFMA phase it hides behind; all GL in
+            // the MFMA phase leave the matrix pipe idle while this wave stalls on them).  The buffer was last read in
+            // R(t-1): retired by the lgkmcnt(0) both groups execute before the barrier that ends their READ phase.
+            const bool rh_now = RH > 0 && t + 3 < nk;
+            if (rh_now) {
+#pragma unroll
+                for (int q = 0; q < RH; ++q) stage_piece(t + 3, q);
+            }
             // wr=1 waits for tile t+1 here, BEFORE it restages in its M phase: staged so far = through t+2
-            // (pair mode: through t+1 at even t, t+2 at odd t)
-            if (wr == 1) G2_WAIT_NEXT(t, pair ? ((t & 1) ? t + 2 : t + 1) : t + 2);
+            // plus the RH early pieces of t+3
+            if (wr == 1) {
+                if (rh_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL + RH) : "memory");
+                else G2_WAIT_NEXT(t, t + 2);
+            }
+            if (RH > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -273,11 +302,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
             // the restage rides in the MFMA phase: an LDS-DMA piece costs 60-180 issue cycles, which made the
             // READ phase (12 ds_read_b128 + 4 pieces) twice as long as the 512-cycle MFMA phase it overlaps.  All pieces
             // in ONE block: one piece between every two fragment rows measured 24 % SLOWER (4096^3: 1172 -> 896 TF).
-            if (!pair) {
-                if (t + 3 < nk) stage(t + 3);
-            } else if ((t & 1) == 0) {
-                if (t + 2 < nk) stage(t + 2);
-                if (t + 3 < nk) stage(t + 3);
+            if (t + 3 < nk) {
+#pragma unroll
+                for (int q = RH; q < GL; ++q) stage_piece(t + 3, q);
+                stage_advance();
             }
 #pragma unroll
             for (int i = 1; i < MI; ++i)
@@ -285,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmArgs a, int ntiles) {
                 for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
-            if (wr == 0) G2_WAIT_NEXT(t, (pair && (t & 1)) ? t + 2 : t + 3);
+            if (wr == 0) G2_WAIT_NEXT(t, t + 3);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);

@@ -310,6 +310,7 @@ int dtf_gemm_bias_act(const void* X, const void* W, const void* bias, int bias_d
     GemmArgs a{(const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)residual,
                (unsigned short*)Y, (unsigned short*)preact, M, N, K, bias_dtype, act,
                (M + GM_BM - 1) / GM_BM, (N + GM_BN - 1) / GM_BN, nullptr};
+    { static int gm = 0; if (gm <= 0) { const char* e = getenv("DTF_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } a.group_m = gm; }
     static bool attr_set = false;
     const int lds = GM_BM * (GM_BN + 4) * 4;     // 67584 B: epilogue tile (>= 64 KB staging)
     const int lds256 = 131072;                   // four 32 KB K-tile buffers
@@ -379,6 +380,7 @@ int dtf_gemm_stats(const void* X, const void* W, void* Y, float* stats, int M, i
     if ((((uintptr_t)X) | ((uintptr_t)W) | ((uintptr_t)Y) | ((uintptr_t)stats)) & 15) return -16;
     GemmArgs a{(const unsigned short*)X, (const unsigned short*)W, nullptr, nullptr, (unsigned short*)Y, nullptr, M, N, K, 0,
                ACT_NONE, (M + G2_BM - 1) / G2_BM, (N + G2_BN - 1) / G2_BN, stats};
+    { static int gm = 0; if (gm <= 0) { const char* e = getenv("DTF_GEMM_GROUP_M"); gm = e ? atoi(e) : 4; if (gm < 1) gm = 1; } a.group_m = gm; }
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {

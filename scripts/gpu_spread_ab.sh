@@ -2,8 +2,8 @@
 # A/B of two builds of the kernel library in one box: libdtf_hip.so vs libdtf_hip_alt.so (GEMM table + K13 shapes)
 set -o pipefail
 export DTF_GEMM_SHAPES="32768,768,768;32768,2304,768;32768,3072,768;32768,768,3072;65536,512,1024;4096,4096,4096;8192,8192,8192"
-for rep in 1 2; do
-for lib in libdtf_hip.so libdtf_hip_alt.so; do
+for rep in ${REPS:-1 2}; do
+for lib in ${LIBS:-libdtf_hip.so libdtf_hip_alt.so}; do
   echo "== $lib"
   DTF_HIP_LIB=$PWD/distributed_tensorflow_amd/ops/$lib timeout -k 10 200 python -u scripts/gemm_bench.py 2>/dev/null | python -c "
 import sys, json
