@@ -144,7 +144,8 @@ class _Conv1x1Fn(torch.autograd.Function):
 # (scripts/conv1x1_stats_bench.py) the saved statistics pass (30-56 us per expand layer) is eaten by K6 being
 # 15-50 us slower than MIOpen's kernels on these memory-bound shapes (9 650 vs 9 680 images/s end to end).
 _STATS = os.environ.get("DTF_CONV1X1_STATS", "0") != "0"
-_STATS_MIN_COUT = 256
+_STATS_MIN_COUT = int(os.environ.get("DTF_CONV1X1_STATS_MIN_COUT", "256"))
+_STATS_K13 = os.environ.get("DTF_CONV1X1_STATS_K13", "1") != "0"
 _stats_declared = False
 
 
@@ -168,6 +169,10 @@ class _Conv1x1StatsFn(torch.autograd.Function):
             hip.declare("dtf_gemm_stats", [P, P, P, P, I, I, I, P])
             _stats_declared = True
         ctx.save_for_backward(x, weight)
+        if _STATS_K13:          # the same pipeline through the convolution entry point: tile picked per problem
+            y, part = conv_fwd(x, weight, (1, 1), (0, 0), stats=True)
+            ctx.mark_non_differentiable(part)
+            return y, part
         cout, cin = weight.shape[0], weight.shape[1]
         N, _, H, W = x.shape
         x2 = _rows(x)
