@@ -27,6 +27,12 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 
 ALIGN = 8  # elements: 16 B in bf16, 32 B in fp32 -> every slice start is 16-B aligned
+# Every VARIABLE starts on a 128-byte line of the flat buffer (64 bf16 elements).  With 16-B alignment one odd-sized
+# variable (ResNet's 1000-element classifier bias, first in pack order) shifted every following weight matrix to
+# 80 B past a line: the 64-B row segments that the GEMM / convolution kernels stage then straddle two lines, and
+# K13's forward calls (weights read in place from this buffer) ran 1.25-1.5x slower than its data-gradient calls
+# (flipped filter in a fresh, aligned allocation) on the same problem.
+PARAM_ALIGN = 64
 
 
 def _round_up(x, m):
@@ -69,7 +75,7 @@ class FlatLayout:
         n_tail, acc = 0, 0
         if tail_elems and tail_elems < bucket_elems:
             for slot in self.slots:
-                acc += _round_up(slot.numel, ALIGN)
+                acc += _round_up(slot.numel, PARAM_ALIGN)
                 if acc > tail_elems:
                     break
                 n_tail += 1
@@ -77,7 +83,7 @@ class FlatLayout:
                 n_tail = 0              # the whole model fits: one ordinary bucket
         open_b = {}                     # group -> [bucket, fill]
         for slot in reversed(self.slots):
-            need = _round_up(slot.numel, ALIGN)
+            need = _round_up(slot.numel, PARAM_ALIGN)
             g = groups[slot.index]
             if slot.index == n_tail - 1:
                 # tail boundary: everything from here on is the exposed tail
@@ -108,7 +114,7 @@ class FlatLayout:
         self.shard_total = shard_off
 
     def _close(self, b, fill):
-        b.size = _round_up(max(fill, 1), self.world * ALIGN)
+        b.size = _round_up(max(fill, 1), self.world * PARAM_ALIGN)      # the next bucket starts on a line too
         b.shard = b.size // self.world
 
     # -- address translation ------------------------------------------------

@@ -189,7 +189,8 @@ def test_sharded_embedding_equals_single_rank(tmp_path, case, world):
     assert many["dropped"] == 0
     torch.testing.assert_close(many["table"], one["table"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(many["acc"], one["acc"], rtol=1e-4, atol=1e-6)
-    torch.testing.assert_close(many["dense"][: one["dense"].numel()].sum(), one["dense"].sum(), rtol=1e-3, atol=1e-3)
+    # flat master incl. its zero padding (bucket ends are rounded per world size, so the two lengths differ)
+    torch.testing.assert_close(many["dense"].sum(), one["dense"].sum(), rtol=1e-3, atol=1e-3)
     assert one["losses"][-1] < one["losses"][0]
 
 

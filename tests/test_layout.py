@@ -1,7 +1,7 @@
 """Flat variable placement (parallel/layout.py): buckets, shards, the small tail bucket."""
 import random
 
-from distributed_tensorflow_amd.parallel.layout import ALIGN, FlatLayout
+from distributed_tensorflow_amd.parallel.layout import ALIGN, PARAM_ALIGN, FlatLayout
 
 
 def _check_invariants(L, named, world):
@@ -13,7 +13,9 @@ def _check_invariants(L, named, world):
     assert sum(b.size for b in L.buckets) == L.total and sum(b.shard for b in L.buckets) == L.shard_total
     for b in L.buckets:
         assert b.size % (world * ALIGN) == 0 and b.shard * world == b.size
+        assert b.start % PARAM_ALIGN == 0
         for i in b.params:
+            assert L.slots[i].flat_off % PARAM_ALIGN == 0          # every variable starts on a 128-byte line (bf16)
             assert b.start <= L.slots[i].flat_off and L.slots[i].flat_off + L.slots[i].numel <= b.start + b.size
     for s in L.slots:
         pieces = L.owner_pieces(s.index)
