@@ -21,7 +21,9 @@ import os
 import shutil
 import tempfile
 
-_SRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gemm_db", "gfx950_tunableop.csv"))
+# DTF_GEMM_DB: another solution file (A/B of a re-tuned file, scripts/gpu_retune.sh)
+_SRC = os.environ.get("DTF_GEMM_DB") or os.path.normpath(
+    os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gemm_db", "gfx950_tunableop.csv"))
 _MAX_DEVICES = 16
 
 
