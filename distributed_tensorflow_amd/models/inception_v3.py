@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct, GradSlices, bn_act_concat
 from ..ops.conv import Conv1x1, Conv2dTN, conv1x1
-from ..ops.pool import avg_pool2d, bn_relu_max_pool2d, max_pool2d
+from ..ops.pool import avg_pool2d, bn_relu_max_pool2d, global_avg_pool, max_pool2d
 
 
 class ConvBN(nn.Module):
@@ -299,7 +299,7 @@ class InceptionV3(nn.Module):
         x = self.Mixed_6e(self.Mixed_6d(self.Mixed_6c(self.Mixed_6b(self.Mixed_6a(x)))))
         aux = self.AuxLogits(x) if (self.AuxLogits is not None and self.training) else None
         x = self.Mixed_7c(self.Mixed_7b(self.Mixed_7a(x)))
-        logits = self.Logits(x.mean((2, 3)))
+        logits = self.Logits(global_avg_pool(x))
         return (logits, aux) if aux is not None else logits
 
 

@@ -215,3 +215,28 @@ def avg_pool2d(x, kernel_size, stride=None, padding=0, count_include_pad=True):
             and x.shape[3] + 2 * padding >= kernel_size):
         return _AvgPoolNHWC.apply(x, int(kernel_size), int(stride), int(padding), bool(count_include_pad))
     return F.avg_pool2d(x, kernel_size, stride, padding, count_include_pad=count_include_pad)
+
+
+class _GlobalAvgPoolNHWC(torch.autograd.Function):
+    """``x.mean((2, 3))`` whose gradient is written directly as a dense NHWC tensor.  Autograd's own backward hands the
+    consumer (a K7 BatchNorm backward) a broadcast view; making that channels_last went through the framework's
+    generic strided copy: 85 us for ResNet-50's [256, 2048, 7, 7] (51 MB), every step."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return x.mean((2, 3))
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+        dx.copy_((dy * (1.0 / (H * W))).view(N, 1, 1, C).expand(N, H, W, C))      # contiguous rows, broadcast source
+        return dx.permute(0, 3, 1, 2)
+
+
+def global_avg_pool(x):
+    """``x.mean((2, 3))`` for an NHWC-dense 4-D tensor (any other input: the framework op)."""
+    if x.dim() == 4 and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last) and x.requires_grad:
+        return _GlobalAvgPoolNHWC.apply(x)
+    return x.mean((2, 3))

@@ -1371,3 +1371,58 @@ def test_linear_residual_layernorm_deferred_bias_matches_fused_path_and_fp32(dev
             torch.testing.assert_close(a, ref, rtol=3e-2, atol=3e-2 * max(1.0, float(ref.abs().max())) * 0.5)
     # the two paths agree with each other far tighter than with fp32 on the bias gradient (same column sum)
     torch.testing.assert_close(outs[0][4], outs[1][4], rtol=2e-2, atol=2e-2 * float(refs[4].abs().max()))
+
+
+@pytest.mark.parametrize("shape,s", [((3, 64, 14, 14), 2), ((2, 256, 9, 7), 2), ((2, 8, 5, 5), 3), ((1, 1024, 14, 14), 2)])
+def test_subsample_fork_kernels_match_strided_ops(dev, shape, s, monkeypatch):
+    """The NHWC subsample / subsample-add kernels behind ``subsample_fork`` against the framework's strided ops (bitwise
+    for the copy; the in-place add rounds once like ``add_``)."""
+    from distributed_tensorflow_amd.ops import conv
+
+    torch.manual_seed(0)
+    outs = []
+    for use in (True, False):
+        monkeypatch.setattr(conv, "_SUBSAMPLE_KERNEL", use)
+        torch.manual_seed(1)
+        x = torch.randn(*shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+        xs, xp = conv.subsample_fork(x, s)
+        assert xs.is_contiguous(memory_format=torch.channels_last)
+        g1 = torch.randn_like(xs).contiguous(memory_format=torch.channels_last)
+        g2 = torch.randn_like(xp).contiguous(memory_format=torch.channels_last)
+        torch.autograd.backward([xs, xp], [g1, g2.clone()])
+        outs.append((xs.detach().clone(), x.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][0], outs[0][0].new_tensor(0) + x.detach()[:, :, ::s, ::s])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_global_avg_pool_backward_is_dense_nhwc(dev):
+    from distributed_tensorflow_amd.ops import pool
+
+    torch.manual_seed(0)
+    x = torch.randn(4, 64, 7, 7, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    x2 = x.detach().clone().requires_grad_()
+    g = torch.randn(4, 64, device=dev).to(torch.bfloat16)
+    y = pool.global_avg_pool(x)
+    y.backward(g)
+    y2 = x2.mean((2, 3))
+    y2.backward(g)
+    assert torch.equal(y, y2)
+    assert x.grad.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(x.grad.float(), x2.grad.float(), rtol=1e-2, atol=1e-3)
+
+
+def test_conv1x1_weight_gradient_has_the_parameter_layout(dev):
+    """K6T's 1x1 weight gradient comes back with the strides of a channels-last parameter (no layout copy before the
+    PS pack / AccumulateGrad)."""
+    from distributed_tensorflow_amd.ops import conv
+
+    torch.manual_seed(0)
+    m = conv.Conv1x1(256, 512).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn(8, 256, 14, 14, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    m(x).sum().backward()
+    assert m.weight.grad.stride() == m.weight.stride()
+    ref = torch.nn.functional.conv2d(x.detach().float().requires_grad_(), m.weight.detach().float().requires_grad_())
+    w2 = m.weight.detach().float().requires_grad_()
+    torch.nn.functional.conv2d(x.detach().float(), w2).sum().backward()
+    assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
