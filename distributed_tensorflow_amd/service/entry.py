@@ -98,6 +98,39 @@ def main(argv=None):
     print("[entry] %s job=%s index=%d ps=%d workers=%d file=%r export=%r" % (
         task_name, job_name, task_index, len(ps_hosts), len(worker_hosts), file_field, export_dir), flush=True)
 
+    # hdfs:// fields (the reference's entry.sh pulls `file` and `data` from HDFS through argv[8] / argv[9],
+    # /root/reference/handlers/train_handler.py:80-83): fetched through the WebHDFS gateway into a task-private
+    # directory before anything runs; an hdfs:// `export` is produced locally and uploaded when the task ends
+    hdfs_web = argv[7]
+    export_remote = None
+    from ..utils import hdfs
+
+    if hdfs.is_remote(file_field) or hdfs.is_remote(data_dir) or hdfs.is_remote(export_dir):
+        import tempfile
+
+        stage = tempfile.mkdtemp(prefix="dtf_hdfs_%s_" % task_name)
+        try:
+            file_field = hdfs.localize(file_field, os.path.join(stage, "file"), hdfs_web)
+            data_dir = hdfs.localize(data_dir, os.path.join(stage, "data"), hdfs_web)
+        except hdfs.HdfsError as e:
+            print("[entry] %s" % e, file=sys.stderr, flush=True)
+            return 2
+        if hdfs.is_remote(export_dir):
+            export_remote, export_dir = hdfs.split(export_dir)[1], os.path.join(stage, "export")
+            os.makedirs(export_dir, exist_ok=True)
+        argv[4], argv[5], argv[6] = file_field, data_dir, export_dir
+        print("[entry] hdfs fields staged under %s" % stage, flush=True)
+
+    def upload_export():
+        if export_remote and os.path.isdir(export_dir) and os.listdir(export_dir):
+            try:
+                hdfs.client_from(hdfs_web).put(export_dir, export_remote)
+                print("[entry] export uploaded to hdfs:%s" % export_remote, flush=True)
+            except hdfs.HdfsError as e:
+                print("[entry] export upload failed: %s" % e, file=sys.stderr, flush=True)
+                return 1
+        return 0
+
     from ..train.jobspec import parse_file_field
 
     try:
@@ -122,7 +155,7 @@ def main(argv=None):
 
         sys.argv = [spec] + argv
         runpy.run_path(spec, run_name="__main__")
-        return 0
+        return upload_export()
 
     opts = spec
     P, W = len(ps_hosts), len(worker_hosts)
@@ -159,6 +192,8 @@ def main(argv=None):
 
     rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,
                   opts=opts, data_dir=data_dir, export_dir=export_dir, metrics=put, t_start=t_start)
+    if rc == 0:
+        rc = upload_export()
     if job_name == "ps":
         print("[entry] ps task finished serving; joining forever (waiting to be reaped)", flush=True)
         ps_join_forever()

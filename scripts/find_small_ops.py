@@ -6,19 +6,21 @@ from distributed_tensorflow_amd.utils import miopen, gemm_tuning
 miopen.setup(); gemm_tuning.setup()
 import torch
 from torch.profiler import profile, ProfilerActivity
-from distributed_tensorflow_amd.models import resnet
+import importlib
+name = sys.argv[1] if len(sys.argv) > 1 else "resnet"
+resnet = importlib.import_module("distributed_tensorflow_amd.models." + name)
 from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
 dev = torch.device("cuda:0")
 model = resnet.prepare(resnet.build(), dev)
 ps = ShardedPS(list(model.named_parameters()), opt=resnet.default_optimizer())
-batch = resnet.synthetic_batch(256, device=dev, seed=1)
+batch = resnet.synthetic_batch(int(sys.argv[2]) if len(sys.argv) > 2 else 256, device=dev, seed=1)
 def step():
     loss = resnet.loss_fn(model, batch); loss.backward(); ps.step()
 for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step(); torch.cuda.synchronize()
-want = ("aten::add", "aten::add_", "aten::copy_", "aten::contiguous", "aten::clone", "aten::fill_", "aten::zero_", "aten::mul", "aten::sum", "aten::mean")
+want = ("aten::index_select", "aten::gather", "aten::cat", "aten::index", "aten::embedding", "aten::masked_fill", "aten::where", "aten::div", "aten::sub", "aten::add", "aten::add_", "aten::copy_", "aten::contiguous", "aten::clone", "aten::fill_", "aten::zero_", "aten::mul", "aten::sum", "aten::mean")
 rows = []
 for e in prof.events():
     if e.name in want and e.device_time_total > 0:
