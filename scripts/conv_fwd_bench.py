@@ -20,7 +20,8 @@ SHAPES = [(256, 64, 56, 56, 64, 3, 3, 1, (1, 1), 6), (256, 128, 56, 56, 128, 3, 
           (256, 64, 35, 35, 96, 3, 3, 1, (1, 1), 8), (256, 96, 35, 35, 96, 3, 3, 1, (1, 1), 6),
           (256, 288, 35, 35, 384, 3, 3, 2, (0, 0), 1), (256, 160, 17, 17, 160, 1, 7, 1, (0, 3), 12), (256, 160, 17, 17, 192, 7, 1, 1, (3, 0), 8),
           (256, 192, 17, 17, 192, 1, 7, 1, (0, 3), 12), (256, 192, 17, 17, 320, 3, 3, 2, (0, 0), 1), (256, 384, 8, 8, 384, 1, 3, 1, (0, 1), 8),
-          (256, 448, 8, 8, 384, 3, 3, 1, (1, 1), 4)]
+          (256, 448, 8, 8, 384, 3, 3, 1, (1, 1), 4),
+          (256, 32, 149, 149, 32, 3, 3, 1, (0, 0), 2), (256, 32, 147, 147, 64, 3, 3, 1, (1, 1), 2)]      # Inception stem 2a / 2b
 VARIANTS = [(4, 8), (4, 7), (4, 6), (4, 5), (4, 4), (3, 8), (3, 7), (3, 6), (3, 5), (3, 4), (2, 8), (2, 4)]
 if os.environ.get("DTF_BENCH_SHAPES"):
     SHAPES = [SHAPES[int(i)] for i in os.environ["DTF_BENCH_SHAPES"].split(",")]
