@@ -479,7 +479,8 @@ def conv_fwd_eligible(x, weight, stride, padding, dilation=(1, 1), groups=1):
     return (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4 and groups == 1
             and tuple(dilation) == (1, 1) and stride[0] == stride[1] and x.shape[1] % 32 == 0 and weight.shape[0] % 8 == 0
             and weight.shape[2] * weight.shape[3] <= 32 and x.is_contiguous(memory_format=torch.channels_last)
-            and weight.is_contiguous(memory_format=torch.channels_last))
+            and weight.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0
+            and weight.data_ptr() % 16 == 0 and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 31) - 256)
 
 
 def conv_fwd(x, weight, stride, padding, stats=False):
