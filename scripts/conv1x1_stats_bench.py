@@ -3,8 +3,10 @@
 in its epilogue then K7 (finalize + apply).  ResNet-50 batch-256 expand / shortcut shapes."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from distributed_tensorflow_amd.utils import miopen
+from distributed_tensorflow_amd.utils import miopen, gemm_tuning
 miopen.setup()
+gemm_tuning.setup()
+os.environ.setdefault("DTF_CONV1X1_STATS", "1")
 import torch
 from distributed_tensorflow_amd.ops import batchnorm as bnmod, conv, hip
 
