@@ -385,6 +385,9 @@ def _wrw_lib():
         hip.declare("dtf_conv_wrw_table_ints", [L], L)
         hip.declare("dtf_conv_wrw_table", [P, I, I, I, I, I, I, I, I, P])
         hip.declare("dtf_conv_wrw", [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P])
+        hip.declare("dtf_conv_wrw_direct_ok", [I, I, I, I, I, I, I, I, I, I])
+        hip.declare("dtf_conv_wrw_direct_workspace", [I, I, I], L)
+        hip.declare("dtf_conv_wrw_direct", [P, P, P, I, P, P, I, I, I, P])
         _wrw_declared = True
     return lib
 
@@ -399,9 +402,24 @@ def conv_wrw_eligible(dy, x, weight, stride, padding, dilation=(1, 1), groups=1)
             and dy.shape[0] * dy.shape[2] * dy.shape[3] < (1 << 24))
 
 
-def conv_wrw_profitable(weight):
-    """Where the module form switches to K6T on its own (``conv_wrw`` itself runs any eligible shape)."""
-    return min(weight.shape[0], weight.shape[1]) >= _CONV_WRW_MIN_CH
+# K14: the direct kernel for the narrow (64 -> 64 channel) 3x3 stride-1 layers (csrc/conv_wrw_direct.hip)
+_CONV_WRW_DIRECT = os.environ.get("DTF_CONV_WRW_DIRECT", "1") != "0"
+
+
+def conv_wrw_direct_ok(x, weight, stride, padding):
+    if not (_CONV_WRW_DIRECT and _CONV_WRW and x.is_cuda):
+        return False
+    cout, cin, kh, kw = weight.shape
+    if (cin, cout, kh, kw) != (64, 64, 3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1):
+        return False
+    return bool(_wrw_lib().dtf_conv_wrw_direct_ok(x.shape[0], x.shape[2], x.shape[3], cin, cout, kh, kw, 1, 1, 1))
+
+
+def conv_wrw_profitable(weight, x=None, stride=(1, 1), padding=(1, 1)):
+    """Where the module form switches to K6T / K14 on its own (``conv_wrw`` itself runs any eligible shape)."""
+    if min(weight.shape[0], weight.shape[1]) >= _CONV_WRW_MIN_CH:
+        return True
+    return x is not None and conv_wrw_direct_ok(x, weight, stride, padding)
 
 
 def conv_wrw(dy, x, weight, stride, padding):
@@ -415,6 +433,21 @@ def conv_wrw(dy, x, weight, stride, padding):
     _, Cout, OH, OW = dy.shape
     KH, KW = weight.shape[2], weight.shape[3]
     dev = x.device
+    if conv_wrw_direct_ok(x, weight, stride, padding):
+        n = int(lib.dtf_conv_wrw_direct_workspace(NB, H, W))
+        ws = _wrw_ws.get(dev)
+        if ws is None or ws.numel() < n:
+            ws = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=dev)
+            _wrw_ws[dev] = ws
+        z = _zero_page.get(dev)
+        if z is None:
+            z = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+            _zero_page[dev] = z
+        dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=dev)
+        rc = lib.dtf_conv_wrw_direct(hip.ptr(dy), hip.ptr(x), hip.ptr(dw), hip.dt(dw), hip.ptr(ws), hip.ptr(z), NB, H, W,
+                                     hip.stream())
+        hip.check(rc, "dtf_conv_wrw_direct")
+        return dw.permute(0, 3, 1, 2)
     n = int(lib.dtf_conv_wrw_workspace(NB * OH * OW, Cout, KH * KW * Cin))
     ws = _wrw_ws.get(dev)
     if ws is None or ws.numel() < n:
@@ -595,7 +628,7 @@ class _ConvFn(torch.autograd.Function):
         if not dy.is_contiguous(memory_format=torch.channels_last):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
-        use_tn = (ctx.needs_input_grad[1] and _CONV_WRW and conv_wrw_profitable(weight)
+        use_tn = (ctx.needs_input_grad[1] and _CONV_WRW and conv_wrw_profitable(weight, x, stride, padding)
                   and conv_wrw_eligible(dy, x, weight, stride, padding))
         use_fwd = ctx.needs_input_grad[0] and _dgrad_as_fwd_ok(x, weight, stride, padding)
         mask = [ctx.needs_input_grad[0] and not use_fwd, ctx.needs_input_grad[1] and not use_tn, False]
@@ -620,7 +653,7 @@ class Conv2dTN(nn.Conv2d):
             return False, False
         k13 = (conv_fwd_profitable(self.in_channels, self.out_channels)
                and conv_fwd_eligible(x, self.weight, self.stride, self.padding))
-        bwd = torch.is_grad_enabled() and ((_CONV_WRW and conv_wrw_profitable(self.weight))
+        bwd = torch.is_grad_enabled() and ((_CONV_WRW and conv_wrw_profitable(self.weight, x, self.stride, self.padding))
                                            or _dgrad_as_fwd_ok(x, self.weight, self.stride, self.padding))
         return k13 or bwd, k13
 
