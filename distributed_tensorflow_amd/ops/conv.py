@@ -386,8 +386,8 @@ def _wrw_lib():
         hip.declare("dtf_conv_wrw_table", [P, I, I, I, I, I, I, I, I, P])
         hip.declare("dtf_conv_wrw", [P, P, P, I, P, P, P, I, I, I, I, I, I, I, I, I, P])
         hip.declare("dtf_conv_wrw_direct_ok", [I, I, I, I, I, I, I, I, I, I])
-        hip.declare("dtf_conv_wrw_direct_workspace", [I, I, I], L)
-        hip.declare("dtf_conv_wrw_direct", [P, P, P, I, P, P, I, I, I, P])
+        hip.declare("dtf_conv_wrw_direct_workspace", [I, I, I, I, I], L)
+        hip.declare("dtf_conv_wrw_direct", [P, P, P, I, P, P, I, I, I, I, I, P])
         _wrw_declared = True
     return lib
 
@@ -402,15 +402,19 @@ def conv_wrw_eligible(dy, x, weight, stride, padding, dilation=(1, 1), groups=1)
             and dy.shape[0] * dy.shape[2] * dy.shape[3] < (1 << 24))
 
 
-# K14: the direct kernel for the narrow (64 -> 64 channel) 3x3 stride-1 layers (csrc/conv_wrw_direct.hip)
+# K14: the direct kernel for the narrow 3x3 stride-1 layers (csrc/conv_wrw_direct.hip); channels in multiples of 64 up to
+# DTF_CONV_WRW_DIRECT_MAX_CH (wider layers have enough output tiles for K6T)
 _CONV_WRW_DIRECT = os.environ.get("DTF_CONV_WRW_DIRECT", "1") != "0"
+_CONV_WRW_DIRECT_MAX_CH = int(os.environ.get("DTF_CONV_WRW_DIRECT_MAX_CH", "128"))
 
 
 def conv_wrw_direct_ok(x, weight, stride, padding):
     if not (_CONV_WRW_DIRECT and _CONV_WRW and x.is_cuda):
         return False
     cout, cin, kh, kw = weight.shape
-    if (cin, cout, kh, kw) != (64, 64, 3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1):
+    if (kh, kw) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or cin % 64 or cout % 64:
+        return False
+    if max(cin, cout) > _CONV_WRW_DIRECT_MAX_CH or x.shape[1] != cin:
         return False
     return bool(_wrw_lib().dtf_conv_wrw_direct_ok(x.shape[0], x.shape[2], x.shape[3], cin, cout, kh, kw, 1, 1, 1))
 
@@ -434,7 +438,7 @@ def conv_wrw(dy, x, weight, stride, padding):
     KH, KW = weight.shape[2], weight.shape[3]
     dev = x.device
     if conv_wrw_direct_ok(x, weight, stride, padding):
-        n = int(lib.dtf_conv_wrw_direct_workspace(NB, H, W))
+        n = int(lib.dtf_conv_wrw_direct_workspace(NB, H, W, Cin, Cout))
         ws = _wrw_ws.get(dev)
         if ws is None or ws.numel() < n:
             ws = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=dev)
@@ -445,7 +449,7 @@ def conv_wrw(dy, x, weight, stride, padding):
             _zero_page[dev] = z
         dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=dev)
         rc = lib.dtf_conv_wrw_direct(hip.ptr(dy), hip.ptr(x), hip.ptr(dw), hip.dt(dw), hip.ptr(ws), hip.ptr(z), NB, H, W,
-                                     hip.stream())
+                                     Cin, Cout, hip.stream())
         hip.check(rc, "dtf_conv_wrw_direct")
         return dw.permute(0, 3, 1, 2)
     n = int(lib.dtf_conv_wrw_workspace(NB * OH * OW, Cout, KH * KW * Cin))

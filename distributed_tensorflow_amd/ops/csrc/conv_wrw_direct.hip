@@ -1,4 +1,5 @@
-// K14: DIRECT weight gradient of the narrow 3x3 stride-1 convolutions (Cin = Cout = 64, NHWC bf16):
+// K14: DIRECT weight gradient of the narrow 3x3 stride-1 convolutions (Cin, Cout multiples of 64, NHWC bf16; a block
+// works on one 64 x 64 channel slice, the blocks are divided among the (Cout / 64) x (Cin / 64) slices):
 //
 //     dW[co][r][s][ci] = sum_{n, h, w} dY[n, h, w, co] * X[n, h + r - 1, w + s - 1, ci]
 //
@@ -26,12 +27,13 @@ typedef __attribute__((address_space(3))) void wd_lds_void;
 typedef const __attribute__((address_space(1))) void wd_glb_void;
 
 #define WD_R 4            // output rows per strip
-#define WD_C 64           // channels (both sides)
+#define WD_C 64           // channels per slice (both sides)
 #define WD_MAXP 16        // LDS-DMA pieces per wave and strip (upper bound of the unrolled staging loop)
 
 struct WdArgs {
     const unsigned short* dy; const unsigned short* x; const unsigned short* zero; float* slab;
     int NB, H, W, P, nch, xpos, ypos, nstrips, strips_per_img, npw;      // npw: pieces per wave (uniform)
+    int Cin, Cout, nsl_ci, nsl, bps;                                     // channel slices; bps: blocks per slice
 };
 
 __device__ __forceinline__ wd_s16x4 wd_tr_read(unsigned addr) {
@@ -58,6 +60,8 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
     const int cig = wave & 3, half = wave >> 2;
     const int P = a.P, W = a.W, H = a.H;
     const int bufbytes = (a.xpos + a.ypos) * 128;
+    const int slice = blockIdx.x % a.nsl, bis = blockIdx.x / a.nsl;       // channel slice of this block, its index inside
+    const int co0 = (slice / a.nsl_ci) * WD_C, ci0 = (slice % a.nsl_ci) * WD_C;
     const int ybase = a.xpos * 128;               // dY image behind the X image inside a buffer
 
     // zero both buffers once: slack positions and padding columns are never written again and must stay finite
@@ -85,14 +89,14 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
         }
         const int d16 = lane & 7;
         const int c = (d16 >> 1) ^ wd_swz(pos);                     // source 32-byte chunk that lands in this slot
-        pc_off[k] = off < 0 ? -1 : off * WD_C + (c * 2 + (d16 & 1)) * 8;
+        pc_off[k] = off < 0 ? -1 : off * (isx ? a.Cin : a.Cout) + (isx ? ci0 : co0) + (c * 2 + (d16 & 1)) * 8;
         pc_row[k] = rl | (isx ? 0 : 256);
         pc_lds[k] = (isx ? 0 : ybase) + (isx ? j : j - nxp) * 1024;
     }
     auto stage = [&](int strip, int buf) {
         const int n = strip / a.strips_per_img, h0 = (strip - n * a.strips_per_img) * WD_R;
-        const unsigned short* xw = a.x + ((int64_t)n * H + (h0 - 1)) * W * WD_C;      // window origin: row h0 - 1
-        const unsigned short* yw = a.dy + ((int64_t)n * H + h0) * W * WD_C;
+        const unsigned short* xw = a.x + ((int64_t)n * H + (h0 - 1)) * W * a.Cin;     // window origin: row h0 - 1
+        const unsigned short* yw = a.dy + ((int64_t)n * H + h0) * W * a.Cout;
         unsigned char* base = smem + buf * bufbytes;
 #pragma unroll
         for (int k = 0; k < WD_MAXP; ++k) {
@@ -131,13 +135,13 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
 #pragma unroll
     for (int k = 0; k < 18; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int strip = blockIdx.x;
+    int strip = bis;
     __syncthreads();                               // the zero fill is complete before the first DMA lands
     if (strip < a.nstrips) stage(strip, 0);
     int it = 0;
-    for (; strip < a.nstrips; strip += gridDim.x, ++it) {
+    for (; strip < a.nstrips; strip += a.bps, ++it) {
         const int buf = it & 1;
-        const int next = strip + gridDim.x;
+        const int next = strip + a.bps;
         if (next < a.nstrips) {
             stage(next, buf ^ 1);                  // streams in under this strip's MFMAs
             // this strip's pieces were issued before the npw of the next one
@@ -199,8 +203,8 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
         __builtin_amdgcn_s_barrier();              // every wave is done with this buffer before it is restaged
     }
 
-    // ---- slab[block][co][tap][ci]; C map of the 16 x 16 fragment: row (co) = 4 g + r, column (ci) = lane & 15
-    float* out = a.slab + (int64_t)blockIdx.x * (9 * WD_C * WD_C);
+    // ---- slab[slice][block in slice][co][tap][ci]; C map of the 16 x 16 fragment: row (co) = 4 g + r, column (ci) = lane & 15
+    float* out = a.slab + ((int64_t)slice * a.bps + bis) * (9 * WD_C * WD_C);
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
         const int tap = half ? 8 - (k >> 2) : (k >> 2), cog = half ? 3 - (k & 3) : (k & 3);
@@ -216,12 +220,14 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
 // walks them alone issues 256 dependent-latency loads (the first version: ~75 us of the kernel pair's 140).  Here a block
 // covers 64 float4 columns x 4 slab lanes; a lane sums the slabs b = lane (mod 4), eight loads in flight, and the four
 // lanes are folded through LDS in lane order.
+// blockIdx.y = channel slice: its slabs are [nb][64][9][64], its results go to out[co0 + co][tap][ci0 + ci] of [Cout][9][Cin].
 __global__ __launch_bounds__(256) void wd_reduce_kernel(const float* __restrict__ slab, int nb, int n4, void* __restrict__ out,
-                                                        int out_dtype) {
+                                                        int out_dtype, int Cin, int nsl_ci) {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int slice = blockIdx.y;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (col < n4) {
-        const f32x4* p = reinterpret_cast<const f32x4*>(slab) + col;
+        const f32x4* p = reinterpret_cast<const f32x4*>(slab) + (int64_t)slice * nb * n4 + col;
         int b = sl;
         for (; b + 28 < nb; b += 32) {
             f32x4 v[8];
@@ -237,17 +243,22 @@ __global__ __launch_bounds__(256) void wd_reduce_kernel(const float* __restrict_
     __syncthreads();
     if (sl != 0 || col >= n4) return;
     s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    // column = (co * 9 + tap) * 16 + ci / 4 inside the slice
+    const int ci4 = col & 15, cotap = col >> 4;
+    const int co0 = (slice / nsl_ci) * WD_C, ci0 = (slice % nsl_ci) * WD_C;
+    const int64_t o = ((int64_t)co0 * 9 + cotap) * Cin + ci0 + ci4 * 4;
     if (out_dtype == DTF_BF16) {
         u32x2 r;
         r[0] = pack_bf16x2(s[0], s[1]);
         r[1] = pack_bf16x2(s[2], s[3]);
-        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + (int64_t)col * 4) = r;
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + o) = r;
     } else {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)col * 4) = s;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + o) = s;
     }
 }
 
-static int wd_plan(int NB, int H, int W, WdArgs* a, int* grid) {
+static int wd_plan(int NB, int H, int W, int Cin, int Cout, WdArgs* a, int* grid) {
+    if (Cin < WD_C || Cout < WD_C || Cin % WD_C || Cout % WD_C || Cin > 256 || Cout > 256) return -1;
     const int P = W + 2;
     const int nch = (WD_R * P + 31) / 32;
     const int xpos = (1 + nch * 32 + 2 * P + 2 + 7) / 8 * 8;      // largest read: position nch*32 - 1 shifted by 2 P + 1 (+ slack)
@@ -264,7 +275,12 @@ static int wd_plan(int NB, int H, int W, WdArgs* a, int* grid) {
     int cu = 0, dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
-    *grid = a->nstrips < cu ? a->nstrips : cu;
+    a->Cin = Cin; a->Cout = Cout; a->nsl_ci = Cin / WD_C; a->nsl = (Cin / WD_C) * (Cout / WD_C);
+    int bps = cu / a->nsl;                                          // blocks per channel slice
+    if (bps > a->nstrips) bps = a->nstrips;
+    if (bps < 1) return -1;
+    a->bps = bps;
+    *grid = bps * a->nsl;
     return 0;
 }
 
@@ -272,27 +288,27 @@ extern "C" {
 
 // 1 when the direct kernel covers this geometry (3x3, stride 1, padding 1, 64 -> 64 channels, strip fits LDS)
 int dtf_conv_wrw_direct_ok(int NB, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int ph, int pw) {
-    if (Cin != WD_C || Cout != WD_C || KH != 3 || KW != 3 || stride != 1 || ph != 1 || pw != 1 || NB < 1 || H < 1 || W < 1) return 0;
+    if (KH != 3 || KW != 3 || stride != 1 || ph != 1 || pw != 1 || NB < 1 || H < 1 || W < 1) return 0;
     WdArgs a{};
     int grid;
-    return wd_plan(NB, H, W, &a, &grid) == 0;
+    return wd_plan(NB, H, W, Cin, Cout, &a, &grid) == 0;
 }
 
 // fp32 workspace floats: one slab per block
-int64_t dtf_conv_wrw_direct_workspace(int NB, int H, int W) {
+int64_t dtf_conv_wrw_direct_workspace(int NB, int H, int W, int Cin, int Cout) {
     WdArgs a{};
     int grid = 0;
-    if (wd_plan(NB, H, W, &a, &grid) != 0) return 0;
+    if (wd_plan(NB, H, W, Cin, Cout, &a, &grid) != 0) return 0;
     return (int64_t)grid * 9 * WD_C * WD_C;
 }
 
-// dw[64][3][3][64] (out_dtype: bf16 / fp32) from dy[NB, H, W, 64] and x[NB, H, W, 64]; zero: >= 16 bytes of zeros
+// dw[Cout][3][3][Cin] (out_dtype: bf16 / fp32) from dy[NB, H, W, Cout] and x[NB, H, W, Cin]; zero: >= 16 bytes of zeros
 int dtf_conv_wrw_direct(const void* dy, const void* x, void* dw, int out_dtype, float* workspace, const void* zero, int NB, int H,
-                        int W, hipStream_t stream) {
+                        int W, int Cin, int Cout, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     WdArgs a{};
     int grid = 0;
-    if (wd_plan(NB, H, W, &a, &grid) != 0) return -80;
+    if (wd_plan(NB, H, W, Cin, Cout, &a, &grid) != 0) return -80;
     if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)workspace) | ((uintptr_t)zero)) & 15) return -16;
     a.dy = (const unsigned short*)dy; a.x = (const unsigned short*)x; a.zero = (const unsigned short*)zero; a.slab = workspace;
     const int lds = 2 * (a.xpos + a.ypos) * 128;
@@ -303,7 +319,8 @@ int dtf_conv_wrw_direct(const void* dy, const void* x, void* dw, int out_dtype, 
     }
     hipLaunchKernelGGL(conv_wrw_direct_kernel, dim3(grid), dim3(512), lds, stream, a);
     const int n4 = 9 * WD_C * WD_C / 4;
-    hipLaunchKernelGGL(wd_reduce_kernel, dim3((n4 + 63) / 64), dim3(256), 0, stream, workspace, grid, n4, dw, out_dtype);
+    hipLaunchKernelGGL(wd_reduce_kernel, dim3((n4 + 63) / 64, a.nsl), dim3(256), 0, stream, workspace, a.bps, n4, dw, out_dtype,
+                       Cin, a.nsl_ci);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -19,15 +19,15 @@ def timeit(fns, n=10, rounds=3):
             b.record(); torch.cuda.synchronize()
             res[i].append(a.elapsed_time(b) / n * 1e3)
     return [round(sorted(r)[len(r) // 2], 1) for r in res]
-for NB, H in [(256, 56), (128, 56), (256, 35)]:
-    x = torch.randn(NB, 64, H, H, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = torch.randn(64, 64, 3, 3, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    dy = torch.randn(NB, 64, H, H, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+for NB, H, C in [(256, 56, 64), (128, 56, 64), (256, 35, 64), (256, 28, 128), (256, 56, 128)]:
+    x = torch.randn(NB, C, H, H, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(C, C, 3, 3, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(NB, C, H, H, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     def k(direct):
         def f():
             conv._CONV_WRW_DIRECT = direct
             conv.conv_wrw(dy, x, w, (1, 1), (1, 1))
         return f
     t = timeit([lambda: torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]), k(False), k(True)])
-    fl = 2.0 * NB * H * H * 64 * 64 * 9
-    print(NB, H, dict(zip(["miopen", "k6t", "k14_direct"], t)), "k14 TF", round(fl / t[2] / 1e6), flush=True)
+    fl = 2.0 * NB * H * H * C * C * 9
+    print(NB, H, C, dict(zip(["miopen", "k6t", "k14_direct"], t)), "k14 TF", round(fl / t[2] / 1e6), flush=True)

@@ -1428,23 +1428,25 @@ def test_conv1x1_weight_gradient_has_the_parameter_layout(dev):
     assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
 
 
-@pytest.mark.parametrize("shape", [(4, 56, 56), (3, 20, 20), (2, 7, 7), (5, 13, 30), (1, 4, 56), (2, 9, 6), (300, 8, 8), (1, 1, 1)])
+@pytest.mark.parametrize("shape", [(4, 56, 56, 64, 64), (3, 20, 20, 64, 64), (2, 7, 7, 64, 64), (5, 13, 30, 64, 64), (1, 4, 56, 64, 64),
+                                   (2, 9, 6, 64, 64), (300, 8, 8, 64, 64), (1, 1, 1, 64, 64), (3, 28, 28, 128, 128), (2, 14, 9, 64, 128),
+                                   (2, 9, 11, 128, 64), (70, 5, 5, 128, 128)])
 def test_conv_wrw_direct_kernel_matches_reference(dev, shape, monkeypatch):
     """K14 (direct 64 -> 64 channel 3x3 weight gradient: flattened strips with the padding in the row pitch, transposing
     LDS reads, the whole filter gradient in registers) against fp32 autograd and against K6T-conv; deterministic."""
     from distributed_tensorflow_amd.ops import conv
 
-    NB, H, W = shape
+    NB, H, W, Cin, Cout = shape
     torch.manual_seed(0)
-    x = torch.randn(NB, 64, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(64, 64, 3, 3, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(NB, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     w2 = w.float().requires_grad_()
     y2 = torch.nn.functional.conv2d(x.float(), w2, None, 1, 1)
     dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     y2.backward(dy.float())
     ref = w2.grad
     assert conv.conv_wrw_direct_ok(x, w, (1, 1), (1, 1))
-    wide = torch.empty(1, 64, 4, 100, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wide = torch.empty(1, Cin, 4, 100, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert not conv.conv_wrw_direct_ok(wide, w, (1, 1), (1, 1))          # two strips of a 100-pixel row do not fit the LDS
     dw = conv.conv_wrw(dy, x, w, (1, 1), (1, 1))
     assert dw.shape == w.shape and dw.is_contiguous(memory_format=torch.channels_last)
@@ -1456,7 +1458,7 @@ def test_conv_wrw_direct_kernel_matches_reference(dev, shape, monkeypatch):
     assert float((dw.float() - old.float()).norm() / old.float().norm()) < 1e-2
     # through the module: a 64-channel layer now takes the own weight-gradient path
     monkeypatch.setattr(conv, "_CONV_WRW_DIRECT", True)
-    m = conv.Conv2dTN(64, 64, 3, padding=1, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    m = conv.Conv2dTN(Cin, Cout, 3, padding=1, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
     with torch.no_grad():
         m.weight.copy_(w)
     x3 = x.clone().requires_grad_()
