@@ -412,7 +412,7 @@ def conv_wrw_direct_ok(x, weight, stride, padding):
     if not (_CONV_WRW_DIRECT and _CONV_WRW and x.is_cuda):
         return False
     cout, cin, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or cin % 64 or cout % 64:
+    if (kh, kw) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or cin % 32 or cout % 32:
         return False
     if max(cin, cout) > _CONV_WRW_DIRECT_MAX_CH or x.shape[1] != cin:
         return False

@@ -89,7 +89,10 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
         }
         const int d16 = lane & 7;
         const int c = (d16 >> 1) ^ wd_swz(pos);                     // source 32-byte chunk that lands in this slot
-        pc_off[k] = off < 0 ? -1 : off * (isx ? a.Cin : a.Cout) + (isx ? ci0 : co0) + (c * 2 + (d16 & 1)) * 8;
+        // channels past the tensor's (a 96-channel layer fills half of its second slice) read zeros
+        const int chn = (isx ? ci0 : co0) + (c * 2 + (d16 & 1)) * 8;
+        if (chn >= (isx ? a.Cin : a.Cout)) off = -1;
+        pc_off[k] = off < 0 ? -1 : off * (isx ? a.Cin : a.Cout) + chn;
         pc_row[k] = rl | (isx ? 0 : 256);
         pc_lds[k] = (isx ? 0 : ybase) + (isx ? j : j - nxp) * 1024;
     }
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
 // lanes are folded through LDS in lane order.
 // blockIdx.y = channel slice: its slabs are [nb][64][9][64], its results go to out[co0 + co][tap][ci0 + ci] of [Cout][9][Cin].
 __global__ __launch_bounds__(256) void wd_reduce_kernel(const float* __restrict__ slab, int nb, int n4, void* __restrict__ out,
-                                                        int out_dtype, int Cin, int nsl_ci) {
+                                                        int out_dtype, int Cin, int Cout, int nsl_ci) {
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
     const int slice = blockIdx.y;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256) void wd_reduce_kernel(const float* __restrict_
     // column = (co * 9 + tap) * 16 + ci / 4 inside the slice
     const int ci4 = col & 15, cotap = col >> 4;
     const int co0 = (slice / nsl_ci) * WD_C, ci0 = (slice % nsl_ci) * WD_C;
+    if (co0 + cotap / 9 >= Cout || ci0 + ci4 * 4 >= Cin) return;      // partial last slices
     const int64_t o = ((int64_t)co0 * 9 + cotap) * Cin + ci0 + ci4 * 4;
     if (out_dtype == DTF_BF16) {
         u32x2 r;
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void wd_reduce_kernel(const float* __restrict_
 }
 
 static int wd_plan(int NB, int H, int W, int Cin, int Cout, WdArgs* a, int* grid) {
-    if (Cin < WD_C || Cout < WD_C || Cin % WD_C || Cout % WD_C || Cin > 256 || Cout > 256) return -1;
+    if (Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32 || Cin > 256 || Cout > 256) return -1;
     const int P = W + 2;
     const int nch = (WD_R * P + 31) / 32;
     const int xpos = (1 + nch * 32 + 2 * P + 2 + 7) / 8 * 8;      // largest read: position nch*32 - 1 shifted by 2 P + 1 (+ slack)
@@ -275,7 +279,7 @@ static int wd_plan(int NB, int H, int W, int Cin, int Cout, WdArgs* a, int* grid
     int cu = 0, dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
-    a->Cin = Cin; a->Cout = Cout; a->nsl_ci = Cin / WD_C; a->nsl = (Cin / WD_C) * (Cout / WD_C);
+    a->Cin = Cin; a->Cout = Cout; a->nsl_ci = (Cin + WD_C - 1) / WD_C; a->nsl = a->nsl_ci * ((Cout + WD_C - 1) / WD_C);
     int bps = cu / a->nsl;                                          // blocks per channel slice
     if (bps > a->nstrips) bps = a->nstrips;
     if (bps < 1) return -1;
@@ -320,7 +324,7 @@ int dtf_conv_wrw_direct(const void* dy, const void* x, void* dw, int out_dtype, 
     hipLaunchKernelGGL(conv_wrw_direct_kernel, dim3(grid), dim3(512), lds, stream, a);
     const int n4 = 9 * WD_C * WD_C / 4;
     hipLaunchKernelGGL(wd_reduce_kernel, dim3((n4 + 63) / 64, a.nsl), dim3(256), 0, stream, workspace, a.bps, n4, dw, out_dtype,
-                       Cin, a.nsl_ci);
+                       Cin, Cout, a.nsl_ci);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -1430,7 +1430,8 @@ def test_conv1x1_weight_gradient_has_the_parameter_layout(dev):
 
 @pytest.mark.parametrize("shape", [(4, 56, 56, 64, 64), (3, 20, 20, 64, 64), (2, 7, 7, 64, 64), (5, 13, 30, 64, 64), (1, 4, 56, 64, 64),
                                    (2, 9, 6, 64, 64), (300, 8, 8, 64, 64), (1, 1, 1, 64, 64), (3, 28, 28, 128, 128), (2, 14, 9, 64, 128),
-                                   (2, 9, 11, 128, 64), (70, 5, 5, 128, 128)])
+                                   (2, 9, 11, 128, 64), (70, 5, 5, 128, 128), (3, 35, 35, 64, 96), (2, 17, 12, 96, 96), (2, 6, 6, 32, 32),
+                                   (2, 10, 10, 96, 32)])
 def test_conv_wrw_direct_kernel_matches_reference(dev, shape, monkeypatch):
     """K14 (direct 64 -> 64 channel 3x3 weight gradient: flattened strips with the padding in the row pitch, transposing
     LDS reads, the whole filter gradient in registers) against fp32 autograd and against K6T-conv; deterministic."""
