@@ -19,6 +19,7 @@ def cat(n):
     if 'bn_fwd_apply' in n: return 'K7 bn fwd apply'
     if 'bn_bwd_apply' in n: return 'K7 bn bwd apply'
     if 'finalize' in n: return 'K7 bn finalize'
+    if 'conv_wrw_direct' in n or 'wd_reduce' in n: return 'K14 conv weight gradient (own direct kernel + slab reduce)'
     if 'gemm256p_kernel' in n and 'true>(GemmArgs' in n: return 'K13 conv fwd / dgrad (own implicit GEMM)'
     if 'gemm_bias_act' in n or 'dtf_gemm' in n or 'gemm256p_kernel' in n: return 'K6 gemm'
     if 'embedding' in n: return 'K3/K4 embedding'
