@@ -21,7 +21,8 @@ import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct, fused_bn2_add_relu
 from ..ops.conv import Conv1x1, Conv2dTN, conv1x1, subsample_fork
-from ..ops.pool import bn_relu_max_pool2d, global_avg_pool
+from ..ops.pool import global_avg_pool
+from ..ops.stem import stem_conv_bn_relu_pool
 
 _SUBSAMPLE = __import__("os").environ.get("DTF_RESNET_SUBSAMPLE", "1") != "0"      # A/B switch
 _DEPTHS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
@@ -119,8 +120,10 @@ class ResNet(nn.Module):
                     nn.init.zeros_(m.bn3.weight)
 
     def forward(self, x):
-        # BatchNorm + ReLU applied inside the pooling kernel: the normalised 112x112 tensor is never materialised
-        x = bn_relu_max_pool2d(self.conv1(x), self.bn1, 3, 2, 1)
+        # K15 stem: direct 7x7 convolution with the BatchNorm statistics in its epilogue, BatchNorm + ReLU applied inside
+        # the pooling kernel (the normalised 112x112 tensor is never materialised), BatchNorm backward inside the
+        # weight-gradient kernel (falls back to conv -> bn_relu_max_pool2d where the kernels do not apply)
+        x = stem_conv_bn_relu_pool(x, self.conv1, self.bn1, 3, 2, 1)
         x = self.block4(self.block3(self.block2(self.block1(x))))
         x = global_avg_pool(x)
         return self.fc(x)

@@ -1216,6 +1216,28 @@ int dtf_bn_fwd_train_pre(const void* x, const void* res, void* y, void* mask, co
     return 0;
 }
 
+// Finalize only, from statistics partials of the producer (plain sums: the K15 stem forward, whose consumer applies the
+// normalisation itself -- ops/stem.py).
+int dtf_bn_finalize_pre(const void* gamma, const void* beta, int param_dtype, float* running_mean, float* running_var,
+                        float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                        const float* partial, int nblk, int64_t M, int C, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0 || nblk <= 0) return -20;
+    const float inv_count = 1.0f / (float)M;
+    const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+    const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
+    if (param_dtype == DTF_BF16)
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C, inv_count,
+                           unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                           (const unsigned short*)nullptr);
+    else
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C, inv_count,
+                           unbias, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                           (const unsigned short*)nullptr);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
 // Inference / frozen-statistics forward: scale/shift precomputed by the caller.
 int dtf_bn_fwd_apply(const void* x, const void* res, void* y, void* mask, const float* scale, const float* shift,
                      int64_t M, int C, int relu, hipStream_t stream) {
@@ -1279,6 +1301,10 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
     else
         hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nred, C,
                            inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
+    if (!dx) {          // reduce + finalize only: the consumer applies dx = k1 dy' + k2 x + k3 itself (K15 stem weight gradient)
+        DTF_CHECK_LAUNCH();
+        return 0;
+    }
     unsigned short *dxs = (unsigned short*)dx, *drs = (unsigned short*)dres;
     const int flat = bn_flat_apply_mode(M, C);
     if (flat) {

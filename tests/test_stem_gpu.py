@@ -1,0 +1,117 @@
+"""K15 (the ResNet stem kernels, ops/csrc/stem_kernels.hip) against plain fp32 PyTorch references."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    return torch.device("cuda", 0)
+
+
+def _inputs(dev, N, H, W, seed=0):
+    torch.manual_seed(seed)
+    x = torch.randn(N, 3, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 3, 7, 7, device=dev) * 147 ** -0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return x, w
+
+
+@pytest.mark.parametrize("cfg", [(2, 224, 224), (3, 64, 72), (1, 37, 88), (2, 7, 64), (5, 96, 104)])
+def test_stem_forward_matches_reference(dev, cfg):
+    """Direct 7x7 / 2 convolution + statistics epilogue vs fp32 conv2d: full-size images, odd heights, column fragments
+    and row strips that end inside the tile, the smallest image."""
+    from distributed_tensorflow_amd.ops import stem
+
+    N, H, W = cfg
+    x, w = _inputs(dev, N, H, W)
+    assert stem.eligible(x, w)
+    ref = F.conv2d(x.float(), w.float(), None, 2, 3)
+    y, part = stem.stem_conv_fwd(x, w)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+    assert float((y.float() - ref).norm() / ref.norm()) < 5e-3
+    yf = y.float()
+    torch.testing.assert_close(part[:, 0].sum(0), yf.sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(part[:, 1].sum(0), (yf * yf).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+
+
+class _Ref(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn = nn.BatchNorm2d(64)
+
+    def forward(self, x):
+        return F.max_pool2d(F.relu(self.bn(self.conv(x))), 3, 2, 1)
+
+
+@pytest.mark.parametrize("cfg", [(4, 64, 64), (2, 224, 224), (3, 40, 72)])
+@pytest.mark.parametrize("fused_wrw", [True, False])
+def test_stem_node_matches_fp32_composition(dev, cfg, fused_wrw, monkeypatch):
+    """The whole stem node (conv + statistics, finalize, BN/ReLU inside the pool; pool gather, BN backward reduction, weight
+    gradient with the BN backward applied on load) vs conv2d -> batch_norm -> relu -> max_pool2d in fp32: output, running
+    statistics, gradients of the filter, gamma and beta."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, stem
+
+    if fused_wrw and not hasattr(stem._lib(), "dtf_stem_wrw"):
+        pytest.skip("fused weight gradient not built")
+    monkeypatch.setattr(stem, "_WRW", fused_wrw)
+    N, H, W = cfg
+    x, w = _inputs(dev, N, H, W, seed=1)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    bn = bnmod.FusedBatchNormAct(64, relu=True).to(dev).to(torch.bfloat16).train()
+    with torch.no_grad():
+        conv.weight.copy_(w)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = _Ref().to(dev).float().train()
+    with torch.no_grad():
+        ref.conv.weight.copy_(conv.weight.float())
+        ref.bn.weight.copy_(bn.weight.float())
+        ref.bn.bias.copy_(bn.bias.float())
+    assert stem.eligible(x, conv.weight)
+    y = stem.stem_conv_bn_relu_pool(x, conv, bn, 3, 2, 1)
+    assert y.grad_fn is not None and "Stem" in type(y.grad_fn).__name__
+    yr = ref(x.float())
+    torch.testing.assert_close(y.float(), yr, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(bn.running_mean.float(), ref.bn.running_mean, rtol=1e-2, atol=1e-3)
+    torch.testing.assert_close(bn.running_var.float(), ref.bn.running_var, rtol=1e-2, atol=1e-3)
+    g = torch.randn_like(yr)
+    y.backward(g.to(torch.bfloat16))
+    yr.backward(g.to(torch.bfloat16).float())
+
+    def rel(a, b):
+        return float((a.float() - b).norm() / b.norm())
+
+    # the filter gradient sees the bf16 rounding of the convolution output through the ReLU mask and the pool's winning
+    # taps (the library path is as far from fp32 as the fused one); the two paths are compared with each other below
+    assert rel(conv.weight.grad, ref.conv.weight.grad) < 1e-1
+    assert rel(bn.weight.grad, ref.bn.weight.grad) < 3e-2
+    assert rel(bn.bias.grad, ref.bn.bias.grad) < 3e-2
+    assert conv.weight.grad.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_stem_fused_weight_gradient_matches_unfused(dev, monkeypatch):
+    """BatchNorm backward applied inside the weight-gradient kernel (fp32 in registers) vs the K7 apply pass (bf16 tensor)
+    + library weight gradient: same operands, so the two agree to bf16 rounding of that one tensor."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, stem
+
+    if not hasattr(stem._lib(), "dtf_stem_wrw"):
+        pytest.skip("fused weight gradient not built")
+    x, w = _inputs(dev, 6, 96, 80, seed=2)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    bn = bnmod.FusedBatchNormAct(64, relu=True).to(dev).to(torch.bfloat16).train()
+    grads = []
+    for fused in (True, False):
+        monkeypatch.setattr(stem, "_WRW", fused)
+        conv.weight.grad = None
+        y = stem.stem_conv_bn_relu_pool(x, conv, bn, 3, 2, 1)
+        torch.manual_seed(5)
+        y.backward(torch.randn_like(y))
+        grads.append(conv.weight.grad.float().clone())
+    assert float((grads[0] - grads[1]).norm() / grads[1].norm()) < 1.5e-2
