@@ -246,6 +246,268 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     else stem_fwd_body<0>(a);
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient with the BatchNorm backward applied on load:
+//
+//     dW[o][r][s][c] = sum_{n, oh, ow} dz[n, oh, ow, o] * X[n, 2 oh - 3 + r, 2 ow - 3 + s, c],
+//     dz = k1[o] * dy' + k2[o] * z + k3[o],   dy' = dy where z * scale[o] + shift[o] > 0, else 0
+//
+// (z: the convolution output, dy: the gradient w.r.t. the BatchNorm + ReLU output, k1..k3: the K7 backward finalize's
+// coefficients) -- the K7 apply pass that would write dz (read 2 x 411 MB, write 411 MB at batch 256) and the library
+// kernel that would read it back (354 us) become ONE pass over dy and z.  GEMM view: M = 64 output channels, N = 147
+// filter elements (10 fragments of 16), K = the pixels.  A block owns strips of R = 2 output rows of one image:
+//   * dy / z / the 9 input rows of the NEXT strip are prefetched into registers while the current strip computes;
+//   * A operand: dz in bf16 as [pixel][64 channels] LDS rows (32-byte chunks XOR-swizzled like K14), read with
+//     ds_read_b64_tr_b16 -- the reduction index is the LDS row;
+//   * B operand: the image rows are re-laid out in LDS as T[input row][t = 3 s + c][ow] = X[row][6 ow - 9 + t] (zero where
+//     that leaves the row), so the 8 consecutive pixels a lane needs of one filter element are 16 contiguous bytes;
+//   * wave w owns the filter-element fragments w, w + 4, w + 8 (12 or 8 accumulators: with 20 per wave plus the
+//     prefetch registers the kernel needed 342 registers and one block per CU); one fp32 slab per block, summed in
+//     fixed order by stem_wrw_reduce_kernel (deterministic).
+// ---------------------------------------------------------------------------
+#define SW_R 2            // output rows per strip
+#define SW_NF 10          // filter-element fragments (16 columns each; 147 of the 160 columns are real)
+#define SW_MAXK 8         // K steps (32 pixels) per strip at most
+#define SW_RAWU 4         // 16-byte pieces of the input rows per thread and strip at most
+
+struct StemWrwArgs {
+    const unsigned short* dy; const unsigned short* z; const unsigned short* x;
+    const float* scale; const float* shift; const float* coef; float* slab;
+    int NB, H, W, OH, OW, strips_per_img, nstrips, ksteps, tpb, cpr, a_bytes, t_bytes;
+};
+
+typedef __attribute__((ext_vector_type(4))) short st_s16x4;
+
+__device__ __forceinline__ int sw_swz(int pos) { return ((pos >> 1) & 1) | (((pos >> 3) & 1) << 1); }
+
+template <int MAXK, int RAWU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void stem_wrw_kernel(StemWrwArgs a) {
+    unsigned char* smem = reinterpret_cast<unsigned char*>(st_smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool has3 = wave < 2;                      // fragments wave, wave + 4 and (waves 0, 1) wave + 8
+    const int OW = a.OW, njg = OW >> 3, nrows_in = 2 * SW_R + 5;
+    const int rowelems = a.W * 3, rowbytes = a.W * 6;
+    unsigned char* regA = smem;
+    unsigned char* regT = smem + a.a_bytes;
+    float* tab = reinterpret_cast<float*>(smem + a.a_bytes + a.t_bytes);      // [5][64]: scale, shift, k1, k2, k3
+    for (int i = tid; i < 5 * ST_C; i += 256) {
+        const int q = i >> 6, c = i & 63;
+        tab[i] = q == 0 ? a.scale[c] : (q == 1 ? a.shift[c] : a.coef[(q - 2) * ST_C + c]);
+    }
+
+    // ---- strip-independent addressing
+    const int i16 = lane & 15, qd = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const unsigned lds0 = (unsigned)(uintptr_t)(st_lds_void*)st_smem;
+    unsigned offA[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * qd + 4 * h + qq;
+#pragma unroll
+        for (int mg = 0; mg < 4; ++mg) offA[mg][h] = lds0 + (unsigned)(row * 128 + ((mg ^ sw_swz(row)) << 5) + 8 * pp);
+    }
+    unsigned kpart[MAXK], npart[3];
+#pragma unroll
+    for (int ks = 0; ks < MAXK; ++ks) {
+        const int G = ks * 4 + qd;
+        int ohl = G / njg, ow0 = (G - ohl * njg) * 8;
+        if (ohl >= SW_R) { ohl = 0; ow0 = 0; }          // K steps past the strip: dz is zero there, any finite operand
+        kpart[ks] = lds0 + (unsigned)(a.a_bytes + (2 * ohl * ST_T) * a.tpb + ow0 * 2);
+    }
+    bool ncol_ok = true;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        int ng = (wave + 4 * f) * 16 + i16;
+        if (f == 2) ncol_ok = ng < ST_KH * ST_T;
+        if (ng > ST_KH * ST_T - 1) ng = ST_KH * ST_T - 1;
+        npart[f] = (unsigned)(ng * a.tpb);
+    }
+    // the T image: 252 threads = 12 x 21: thread -> filter-row element t, (input row, 8-pixel group) pairs sub, sub + 12, ..
+    const int tt = tid % ST_T, tsub = tid / ST_T;
+
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int mg = 0; mg < 4; ++mg)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) acc[mg][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- register prefetch of one strip: dy / z (position (tid >> 3) + 32 u, channels 8 (tid & 7) ..) and the input rows
+    u32x4 rdy[MAXK], rz[MAXK], rraw[RAWU];
+    const int chunk8 = tid & 7, c0 = chunk8 * 8;
+    auto prefetch = [&](int strip) {
+        const int n = strip / a.strips_per_img, oh0 = (strip - n * a.strips_per_img) * SW_R;
+        const int vrows = a.OH - oh0 < SW_R ? a.OH - oh0 : SW_R;
+        // the input rows first: they are consumed first (vmcnt retires in order)
+        const int ih0 = 2 * oh0 - 3;
+#pragma unroll
+        for (int u = 0; u < RAWU; ++u) {
+            const int idx = tid + 256 * u;
+            rraw[u] = (u32x4){0u, 0u, 0u, 0u};
+            if (idx < nrows_in * a.cpr) {
+                const int row = idx / a.cpr, ch = idx - row * a.cpr, ih = ih0 + row;
+                if ((unsigned)ih < (unsigned)a.H)
+                    rraw[u] = *reinterpret_cast<const u32x4*>(a.x + ((int64_t)n * a.H + ih) * rowelems + ch * 8);
+            }
+        }
+        const int64_t base = (((int64_t)n * a.OH + oh0) * OW) * ST_C + c0;
+#pragma unroll
+        for (int u = 0; u < MAXK; ++u) {
+            const int pos = (tid >> 3) + 32 * u;
+            rdy[u] = (u32x4){0u, 0u, 0u, 0u};
+            rz[u] = (u32x4){0u, 0u, 0u, 0u};
+            if (u < a.ksteps && pos < vrows * OW) {
+                rdy[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.dy + base + (int64_t)pos * ST_C));
+                rz[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a.z + base + (int64_t)pos * ST_C));
+            }
+        }
+    };
+
+    int strip = blockIdx.x;
+    if (strip < a.nstrips) prefetch(strip);
+    for (; strip < a.nstrips; strip += gridDim.x) {
+        const int n = strip / a.strips_per_img, oh0 = (strip - n * a.strips_per_img) * SW_R;
+        const int vrows = a.OH - oh0 < SW_R ? a.OH - oh0 : SW_R;
+        // 1. the input rows, as they are, into region A
+#pragma unroll
+        for (int u = 0; u < RAWU; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < nrows_in * a.cpr) {
+                const int row = idx / a.cpr, ch = idx - row * a.cpr;
+                *reinterpret_cast<u32x4*>(regA + row * rowbytes + ch * 16) = rraw[u];
+            }
+        }
+        __syncthreads();
+        // 2. T[i][t][ow] = X[i][6 ow - 9 + t]
+        if (tid < 12 * ST_T) {
+            for (int ij = tsub; ij < nrows_in * njg; ij += 12) {
+                const int i = ij / njg, jg = ij - i * njg;
+                const unsigned short* rawrow = reinterpret_cast<const unsigned short*>(regA + i * rowbytes);
+                const int e0 = 48 * jg + tt - 9;
+                unsigned v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = e0 + 6 * k;
+                    const bool ok = (unsigned)e < (unsigned)rowelems;
+                    const unsigned val = rawrow[ok ? e : 0];
+                    v[k] = ok ? val : 0u;
+                }
+                u32x4 o;
+                o[0] = v[0] | (v[1] << 16); o[1] = v[2] | (v[3] << 16); o[2] = v[4] | (v[5] << 16); o[3] = v[6] | (v[7] << 16);
+                *reinterpret_cast<u32x4*>(regT + (i * ST_T + tt) * a.tpb + jg * 16) = o;
+            }
+        }
+        __syncthreads();
+        // 3. dz from the prefetched dy / z, bf16, into region A (over the raw rows)
+        {
+            float sc[8], sh[8], k1[8], k2[8], k3[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sc[k] = tab[0 * ST_C + c0 + k]; sh[k] = tab[1 * ST_C + c0 + k];
+                k1[k] = tab[2 * ST_C + c0 + k]; k2[k] = tab[3 * ST_C + c0 + k]; k3[k] = tab[4 * ST_C + c0 + k];
+            }
+#pragma unroll
+            for (int u = 0; u < MAXK; ++u) {
+                if (u < a.ksteps) {
+                    const int pos = (tid >> 3) + 32 * u;
+                    u32x4 o = {0u, 0u, 0u, 0u};
+                    if (pos < vrows * OW) {
+                        float f[8];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float z0 = __uint_as_float(rz[u][k] << 16), z1 = __uint_as_float(rz[u][k] & 0xffff0000u);
+                            float g0 = __uint_as_float(rdy[u][k] << 16), g1 = __uint_as_float(rdy[u][k] & 0xffff0000u);
+                            g0 = fmaf(z0, sc[2 * k], sh[2 * k]) > 0.f ? g0 : 0.f;
+                            g1 = fmaf(z1, sc[2 * k + 1], sh[2 * k + 1]) > 0.f ? g1 : 0.f;
+                            f[2 * k] = fmaf(k1[2 * k], g0, fmaf(k2[2 * k], z0, k3[2 * k]));
+                            f[2 * k + 1] = fmaf(k1[2 * k + 1], g1, fmaf(k2[2 * k + 1], z1, k3[2 * k + 1]));
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(f[2 * k], f[2 * k + 1]);
+                    }
+                    *reinterpret_cast<u32x4*>(regA + pos * 128 + (((chunk8 >> 1) ^ sw_swz(pos)) << 5) + (chunk8 & 1) * 16) = o;
+                }
+            }
+        }
+        // 4. the next strip streams into the registers under the MFMAs
+        if (strip + (int)gridDim.x < a.nstrips) prefetch(strip + gridDim.x);
+        __syncthreads();
+        // 5. the K steps
+#pragma unroll
+        for (int ks = 0; ks < MAXK; ++ks) {
+            if (ks < a.ksteps) {
+                st_s16x4 la[4], ha[4];
+                st_s16x8 fb[3];
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(la[mg]) : "v"(offA[mg][0]), "n"(ks * 4096));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ha[mg]) : "v"(offA[mg][1]), "n"(ks * 4096));
+                }
+#pragma unroll
+                for (int f = 0; f < 3; ++f)      // (waves 2, 3 read a third fragment they do not use: every asm output stays live)
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(fb[f]) : "v"(kpart[ks] + npart[f]));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (!ncol_ok) fb[2] = (st_s16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int mg = 0; mg < 4; ++mg) {
+                    const st_s16x8 fa = __builtin_shufflevector(la[mg], ha[mg], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[mg][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[0], acc[mg][0], 0, 0, 0);
+                    acc[mg][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[1], acc[mg][1], 0, 0, 0);
+                    if (has3) acc[mg][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[2], acc[mg][2], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();            // every wave is done with regions A and T before the next strip rewrites them
+    }
+
+    // ---- one slab [64][160] per block.  C map of a fragment: row (output channel) = 16 mg + 4 qd + i, column (filter
+    // element) = 16 (wave + 4 f) + i16
+    float* out = a.slab + (int64_t)blockIdx.x * (ST_C * SW_NF * 16);
+#pragma unroll
+    for (int mg = 0; mg < 4; ++mg)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            if (f == 2 && !has3) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                out[(mg * 16 + 4 * qd + i) * (SW_NF * 16) + (wave + 4 * f) * 16 + i16] = acc[mg][f][i];
+        }
+}
+
+// dw[o][147] (bf16 / fp32, the channels-last parameter layout) = sum over the blocks' slabs in a fixed order: a block
+// covers 64 float4 columns x 4 slab lanes (the K14 reduce)
+__global__ __launch_bounds__(256) void stem_wrw_reduce_kernel(const float* __restrict__ slab, int nb, void* __restrict__ dw,
+                                                              int out_dtype) {
+    const int n4 = ST_C * SW_NF * 16 / 4;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < n4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(slab) + col;
+        int b = sl;
+        for (; b + 28 < nb; b += 32) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(b + 4 * u) * n4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nb; b += 4) s += p[(int64_t)b * n4];
+    }
+    __shared__ f32x4 red[4][64];
+    red[sl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sl != 0 || col >= n4) return;
+    s = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    const int o = col / (SW_NF * 4), nq = (col - o * (SW_NF * 4)) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nn = nq + i;
+        if (nn >= ST_KH * ST_T) continue;
+        if (out_dtype == DTF_BF16) reinterpret_cast<unsigned short*>(dw)[o * (ST_KH * ST_T) + nn] = f32_to_bf16(s[i]);
+        else reinterpret_cast<float*>(dw)[o * (ST_KH * ST_T) + nn] = s[i];
+    }
+}
+
 static int stem_blocks(int nstrips) {
     int cu = 0, dev = 0;
     (void)hipGetDevice(&dev);
@@ -280,6 +542,33 @@ static int stem_fwd_plan(int NB, int H, int W, StemFwdArgs* a, int* lds) {
     if (*lds > 81920) return -1;
     if ((int64_t)NB * a->strips_per_img > 0x7fffffff) return -1;
     a->nstrips = NB * a->strips_per_img;
+    return 0;
+}
+
+
+static int stem_wrw_plan(int NB, int H, int W, StemWrwArgs* a, int* lds, int* grid) {
+    if (NB < 1 || H < 7 || W < 64 || (W & 15) || W > 256) return -1;
+    a->NB = NB; a->H = H; a->W = W;
+    a->OH = (H - 1) / 2 + 1;
+    a->OW = W / 2;
+    a->strips_per_img = (a->OH + SW_R - 1) / SW_R;
+    a->nstrips = NB * a->strips_per_img;
+    a->ksteps = (SW_R * a->OW + 31) / 32;
+    if (a->ksteps > SW_MAXK) return -1;
+    a->tpb = a->OW * 2 + 16;
+    a->cpr = W * 6 / 16;
+    if ((2 * SW_R + 5) * a->cpr > 256 * SW_RAWU) return -1;
+    int ab = a->ksteps * 4096;
+    if (ab < (2 * SW_R + 5) * W * 6) ab = (2 * SW_R + 5) * W * 6;
+    a->a_bytes = (ab + 15) & ~15;
+    a->t_bytes = (2 * SW_R + 5) * ST_T * a->tpb;
+    *lds = a->a_bytes + a->t_bytes + 5 * ST_C * 4;
+    if (*lds > 163840) return -1;
+    int cu = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+    const int per_cu = 163840 / *lds >= 2 ? 2 : 1;
+    *grid = cu * per_cu < a->nstrips ? cu * per_cu : a->nstrips;
     return 0;
 }
 
@@ -325,6 +614,48 @@ int dtf_stem_fwd(const void* x, const void* wp, void* y, float* partial, const v
         attr = true;
     }
     hipLaunchKernelGGL(stem_fwd_kernel, dim3(stem_blocks(a.nstrips)), dim3(256), lds, stream, a);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// 1 when the fused weight-gradient kernel covers this image size
+int dtf_stem_wrw_ok(int NB, int H, int W) {
+    StemWrwArgs a{};
+    int lds, grid;
+    return stem_wrw_plan(NB, H, W, &a, &lds, &grid) == 0;
+}
+
+// fp32 workspace floats: one [64][160] slab per block
+int64_t dtf_stem_wrw_workspace(int NB, int H, int W) {
+    StemWrwArgs a{};
+    int lds, grid = 0;
+    if (stem_wrw_plan(NB, H, W, &a, &lds, &grid) != 0) return 0;
+    return (int64_t)grid * ST_C * SW_NF * 16;
+}
+
+// dw[64][7][7][3] (out_dtype: bf16 / fp32) from dy, z [NB, OH, OW, 64], x [NB, H, W, 3] and the BatchNorm backward's
+// per-channel terms (scale, shift: the forward's; coef: [3][64] of the K7 backward finalize)
+int dtf_stem_wrw(const void* dy, const void* z, const void* x, const float* scale, const float* shift, const float* coef,
+                 void* dw, int out_dtype, float* workspace, int NB, int H, int W, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    StemWrwArgs a{};
+    int lds = 0, grid = 0;
+    if (stem_wrw_plan(NB, H, W, &a, &lds, &grid) != 0) return -80;
+    if ((((uintptr_t)dy) | ((uintptr_t)z) | ((uintptr_t)x) | ((uintptr_t)workspace)) & 15) return -16;
+    a.dy = (const unsigned short*)dy; a.z = (const unsigned short*)z; a.x = (const unsigned short*)x;
+    a.scale = scale; a.shift = shift; a.coef = coef; a.slab = workspace;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)stem_wrw_kernel<7, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)stem_wrw_kernel<SW_MAXK, SW_RAWU>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        attr = true;
+    }
+    if (a.ksteps <= 7 && (2 * SW_R + 5) * a.cpr <= 256 * 3)
+        hipLaunchKernelGGL((stem_wrw_kernel<7, 3>), dim3(grid), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((stem_wrw_kernel<SW_MAXK, SW_RAWU>), dim3(grid), dim3(256), lds, stream, a);
+    const int n4 = ST_C * SW_NF * 16 / 4;
+    hipLaunchKernelGGL(stem_wrw_reduce_kernel, dim3((n4 + 63) / 64), dim3(256), 0, stream, workspace, grid, dw, out_dtype);
     DTF_CHECK_LAUNCH();
     return 0;
 }

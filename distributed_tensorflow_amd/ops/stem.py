@@ -37,6 +37,7 @@ def _lib():
         hip.declare("dtf_stem_fwd", [P, P, P, P, P, I, I, I, P])
         hip.declare("dtf_bn_finalize_pre", [P, P, I, P, P, Fl, Fl, P, P, P, P, P, I, L, I, P])
         if hasattr(lib, "dtf_stem_wrw"):
+            hip.declare("dtf_stem_wrw_ok", [I, I, I], I)
             hip.declare("dtf_stem_wrw_workspace", [I, I, I], L)
             hip.declare("dtf_stem_wrw", [P, P, P, P, P, P, P, I, P, I, I, I, P])
         _declared = True
@@ -125,7 +126,8 @@ class _StemFn(torch.autograd.Function):
         hip.check(rc, "dtf_maxpool_bwd")
         dgb = torch.empty(2, C, dtype=gamma.dtype, device=dev)
         coef = torch.empty(3, C, dtype=torch.float32, device=dev)
-        fused = _WRW and hasattr(lib, "dtf_stem_wrw") and ctx.needs_input_grad[1]
+        fused = bool(_WRW and hasattr(lib, "dtf_stem_wrw") and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                     and lib.dtf_stem_wrw_ok(N, x.shape[2], x.shape[3]))
         dc = None if fused else torch.empty((N, C, H, W), dtype=dy.dtype, device=dev, memory_format=torch.channels_last)
         rc = bnmod._lib().dtf_bn_bwd_train(
             hip.ptr(dbn), hip.ptr(c), None, hip.ptr(gamma), hip.dt(gamma), stats[0].data_ptr(), stats[1].data_ptr(),
@@ -146,8 +148,6 @@ class _StemFn(torch.autograd.Function):
                                                                [False, True, False])
         dx = None
         if ctx.needs_input_grad[0]:          # an image that wants a gradient: not the training path, library kernel
-            if dc is None:
-                raise RuntimeError("stem: input gradient requested with the fused weight-gradient path (set DTF_STEM_WRW=0)")
             dx, _, _ = torch.ops.aten.convolution_backward(dc, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
                                                            [True, False, False])
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None
