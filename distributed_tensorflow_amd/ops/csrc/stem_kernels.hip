@@ -30,7 +30,7 @@ typedef const __attribute__((address_space(1))) void st_glb_void;
 
 struct StemFwdArgs {
     const unsigned short* x; const unsigned short* wp; const unsigned short* zero; unsigned short* y; float* partial;
-    int NB, H, W, OH, OW, R, strips_per_img, nstrips, pitch, nrows, owf, bufbytes, npieces, npw, dbg;
+    int NB, H, W, OH, OW, R, strips_per_img, nstrips, pitch, nrows, owf, bufbytes, npieces, npw;
 };
 
 __device__ __forceinline__ float st_row16_sum(float v) {      // sum over the 16 lanes of a DPP row (lane & 15)
@@ -201,8 +201,8 @@ __device__ __forceinline__ void stem_fwd_body(const StemFwdArgs& a) {
                 o0[0] = pack_bf16x2(acc[0][0], acc[0][1]); o0[1] = pack_bf16x2(acc[0][2], acc[0][3]);
                 o0[2] = pack_bf16x2(acc[1][0], acc[1][1]); o0[3] = pack_bf16x2(acc[1][2], acc[1][3]);
                 unsigned short* yp = a.y + (((int64_t)n * a.OH + oh) * a.OW + ow) * ST_C + chalf * 32 + qd * 8;
-                if (!(a.dbg & 1)) *reinterpret_cast<u32x4*>(yp) = o0;
-                if (!(a.dbg & 2)) {
+                *reinterpret_cast<u32x4*>(yp) = o0;
+                {
                 // statistics of what the consumer reads: the rounded values
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -606,7 +606,6 @@ int dtf_stem_fwd(const void* x, const void* wp, void* y, float* partial, const v
     if (stem_fwd_plan(NB, H, W, &a, &lds) != 0) return -80;
     if ((((uintptr_t)x) | ((uintptr_t)wp) | ((uintptr_t)y) | ((uintptr_t)partial) | ((uintptr_t)zero)) & 15) return -16;
     a.zero = (const unsigned short*)zero;
-    { const char* e = getenv("DTF_STEM_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wp; a.y = (unsigned short*)y; a.partial = partial;
     static bool attr = false;
     if (!attr) {
