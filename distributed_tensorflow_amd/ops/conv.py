@@ -490,9 +490,22 @@ _CONV_FWD_MIN_CH = int(os.environ.get("DTF_CONV_FWD_MIN_CH", "160"))
 _CONV_FWD_STATS = os.environ.get("DTF_CONV_FWD_STATS", "1") != "0"
 
 
-def conv_fwd_profitable(cin, cout):
+# K16 (csrc/conv3x3_c64_kernels.hip): direct kernel of the 64 -> 64 channel 3x3 stride-1 layers (ResNet stage 1), forward
+# and data gradient: 62-66 us vs MIOpen 107-112 us at batch 256, 56 x 56, and the BatchNorm statistics ride in its epilogue
+_CONV_C64 = os.environ.get("DTF_CONV_C64", "1") != "0"
+
+
+def conv_c64_shape(weight, stride, padding):
+    """The layer shape K16 covers (tensor checks: :func:`conv_fwd_eligible`)."""
+    return (_CONV_C64 and _CONV_FWD != "0" and tuple(weight.shape) == (64, 64, 3, 3) and tuple(stride) == (1, 1)
+            and tuple(padding) == (1, 1))
+
+
+def conv_fwd_profitable(cin, cout, weight=None, stride=None, padding=None):
     if _CONV_FWD == "0":
         return False
+    if weight is not None and conv_c64_shape(weight, stride, padding):
+        return True
     return _CONV_FWD == "all" or min(cin, cout) >= _CONV_FWD_MIN_CH
 
 
@@ -508,6 +521,9 @@ def _fwd_lib():
         hip.declare("dtf_conv_fwd_stats_blocks", [L, I], L)
         hip.declare("dtf_conv_fwd_set_tile", [I, I], None)
         hip.declare("dtf_conv_fwd", [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, P])
+        hip.declare("dtf_conv3x3_c64_ok", [I, I, I], I)
+        hip.declare("dtf_conv3x3_c64_blocks", [I, I, I], L)
+        hip.declare("dtf_conv3x3_c64", [P, P, P, P, P, I, I, I, P])
         _fwd_declared = True
     return lib
 
@@ -539,6 +555,14 @@ def conv_fwd(x, weight, stride, padding, stats=False):
         _zero_page[dev] = z
     y = torch.empty((NB, OH, OW, Cout), dtype=torch.bfloat16, device=dev)
     part = None
+    if conv_c64_shape(weight, stride, padding) and lib.dtf_conv3x3_c64_ok(NB, H, W):
+        if stats:
+            part = torch.empty(int(lib.dtf_conv3x3_c64_blocks(NB, H, W)), 2, Cout, dtype=torch.float32, device=dev)
+        rc = lib.dtf_conv3x3_c64(hip.ptr(x), hip.ptr(weight), hip.ptr(z), hip.ptr(y), hip.ptr(part) if stats else None, NB, H, W,
+                                 hip.stream())
+        hip.check(rc, "dtf_conv3x3_c64")
+        y = y.permute(0, 3, 1, 2)
+        return (y, part) if stats else y
     if stats:
         part = torch.empty(int(lib.dtf_conv_fwd_stats_blocks(NB * OH * OW, Cout)), 2, Cout, dtype=torch.float32, device=dev)
     rc = lib.dtf_conv_fwd(hip.ptr(x), hip.ptr(weight), hip.ptr(z), hip.ptr(y), hip.ptr(part) if stats else None, NB, H, W, Cin,
@@ -598,7 +622,7 @@ def dgrad_as_forward(dy, weight, padding):
     else:
         wt = weight.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
     pad = (kh - 1 - padding[0], kw - 1 - padding[1])
-    if conv_fwd_profitable(cout, cin) and conv_fwd_eligible(dy, wt, (1, 1), pad):
+    if conv_fwd_profitable(cout, cin, wt, (1, 1), pad) and conv_fwd_eligible(dy, wt, (1, 1), pad):
         return conv_fwd(dy, wt, (1, 1), pad)
     return F.conv2d(dy, wt, None, 1, pad)
 
@@ -614,7 +638,8 @@ class _ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.geom = (stride, padding)
         ctx.set_materialize_grads(False)          # no zero-filled "gradient" of the statistics output
-        if conv_fwd_profitable(weight.shape[1], weight.shape[0]) and conv_fwd_eligible(x, weight, stride, padding):
+        if (conv_fwd_profitable(weight.shape[1], weight.shape[0], weight, stride, padding)
+                and conv_fwd_eligible(x, weight, stride, padding)):
             if stats:
                 y, part = conv_fwd(x, weight, stride, padding, stats=True)
                 ctx.mark_non_differentiable(part)
@@ -655,7 +680,7 @@ class Conv2dTN(nn.Conv2d):
         if not (self.bias is None and self.groups == 1 and x.is_cuda and x.dtype == torch.bfloat16
                 and isinstance(self.padding, tuple) and self.dilation == (1, 1)):
             return False, False
-        k13 = (conv_fwd_profitable(self.in_channels, self.out_channels)
+        k13 = (conv_fwd_profitable(self.in_channels, self.out_channels, self.weight, self.stride, self.padding)
                and conv_fwd_eligible(x, self.weight, self.stride, self.padding))
         bwd = torch.is_grad_enabled() and ((_CONV_WRW and conv_wrw_profitable(self.weight, x, self.stride, self.padding))
                                            or _dgrad_as_fwd_ok(x, self.weight, self.stride, self.padding))

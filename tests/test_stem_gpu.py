@@ -115,3 +115,57 @@ def test_stem_fused_weight_gradient_matches_unfused(dev, monkeypatch):
         y.backward(torch.randn_like(y))
         grads.append(conv.weight.grad.float().clone())
     assert float((grads[0] - grads[1]).norm() / grads[1].norm()) < 1.5e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K16: direct 64 -> 64 channel 3x3 convolution (ops/csrc/conv3x3_c64_kernels.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(2, 56, 56), (3, 17, 23), (1, 16, 16), (2, 9, 40), (5, 28, 28), (1, 3, 98)])
+def test_conv3x3_c64_matches_reference(dev, cfg):
+    """Forward + statistics epilogue vs fp32 conv2d: fragments that wrap around a row end, strips that end inside the
+    image, odd widths, the smallest width."""
+    from distributed_tensorflow_amd.ops import conv
+
+    N, H, W = cfg
+    torch.manual_seed(0)
+    x = torch.randn(N, 64, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 64, 3, 3, device=dev) * 576 ** -0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert conv.conv_c64_shape(w, (1, 1), (1, 1)) and conv.conv_fwd_eligible(x, w, (1, 1), (1, 1))
+    assert conv._fwd_lib().dtf_conv3x3_c64_ok(N, H, W)
+    ref = F.conv2d(x.float(), w.float(), None, 1, 1)
+    y, part = conv.conv_fwd(x, w, (1, 1), (1, 1), stats=True)
+    y0 = conv.conv_fwd(x, w, (1, 1), (1, 1))
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+    assert float((y.float() - ref).norm() / ref.norm()) < 5e-3
+    assert torch.equal(y, y0)
+    yf = y.float()
+    torch.testing.assert_close(part[:, 0].sum(0), yf.sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(part[:, 1].sum(0), (yf * yf).sum((0, 2, 3)), rtol=1e-4, atol=2e-2)
+
+
+def test_conv3x3_c64_module_forward_backward(dev):
+    """Conv2dTN(64, 64, 3) routed to K16 (forward, data gradient as a forward convolution of dY with the flipped filter,
+    BatchNorm fed from the epilogue statistics) against the fp32 composition."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, conv
+
+    torch.manual_seed(0)
+    x = torch.randn(4, 64, 20, 24, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    m = conv.Conv2dTN(64, 64, 3, stride=1, padding=1, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    bn = bnmod.FusedBatchNormAct(64, relu=True).to(dev).to(torch.bfloat16).train()
+    x2, w2 = x.detach().float().requires_grad_(), m.weight.detach().float().requires_grad_()
+    c2 = F.conv2d(x2, w2, None, 1, 1)
+    r2 = F.relu(F.batch_norm(c2, None, None, bn.weight.detach().float(), bn.bias.detach().float(), True, 0.1, bn.eps))
+    c, st = m.forward_stats(x)
+    assert st is not None
+    r = bn(c, stats=st)
+    torch.testing.assert_close(r.float(), r2, rtol=3e-2, atol=3e-2)
+    g = torch.randn_like(r2)
+    r.backward(g.to(torch.bfloat16))
+    r2.backward(g.to(torch.bfloat16).float())
+
+    def rel(a, b):
+        return float((a.float() - b).norm() / b.norm())
+
+    assert rel(x.grad, x2.grad) < 3e-2
+    assert rel(m.weight.grad, w2.grad) < 3e-2
