@@ -36,12 +36,15 @@ __device__ __forceinline__ float c3_row16_sum(float v) {      // sum over the 16
 
 extern __shared__ __attribute__((aligned(16))) unsigned c3_smem[];
 
+// PB: row pitch in bytes (P * 128, P a multiple of 8 slots): the filter row's immediate read offset must be a constant
+template <int PB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(C3Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fg = wave & 1, chalf = wave >> 1;
     const int i16 = lane & 15, qd = lane >> 4;
-    const int P = a.P, W = a.W;
+    constexpr int P = PB / 128;
+    const int W = a.W;
 
     // ---- staging: piece j = LDS positions 8 j .. 8 j + 7 (a position = one pixel slot of 128 bytes; row i of the strip
     // window holds slots 0 .. W + 1, slot 0 and W + 1 are the zero padding); lane -> position 8 j + (lane >> 3), physical
@@ -106,63 +109,94 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_sched_barrier(0);
         const int n = strip / a.strips_per_img, oh0 = (strip - n * a.strips_per_img) * a.R;
         const unsigned bufa = lds0 + (unsigned)(buf * a.bufbytes);
-        for (int f = fg; f < a.nfr; f += 2) {
-            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            const int l0 = 16 * f;
-            const int ohl0 = l0 / W;                                 // wave-uniform
-            int ow = l0 - ohl0 * W + i16, ohl = ohl0;
-            if (ow >= W) { ow -= W; ++ohl; }                         // W >= 16: a fragment spans at most two rows
-            const bool inside = ohl < a.R;                           // the last fragment may run past the strip
-            if (!inside) ohl = a.R - 1;
-            const int posb = ohl * P + ow;                           // tap (0, 0): window row ohl, slot ow
-            // (inline asm: every register an asm read writes stays live until the wait.  Three batches of three taps in two
-            // register sets: a batch's reads fly under the previous batch's MFMAs; a set is reloaded only after the MFMAs
-            // that read it have all been ISSUED -- they fetch their operands in their first passes, an LDS read returns
-            // 64+ cycles later)
-            c3_s16x8 fa[3][2], fb[3][2];
-#define C3_READ(DST, T0)                                                                                  \
-            _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                \
-                const int tap = T0 + t, r = tap / 3, s = tap - 3 * r;                                      \
-                const int pos = posb + r * P + s;                                                          \
-                const unsigned off = (unsigned)(pos * 128 + ((qd ^ (pos & 7)) << 4));                      \
-                asm volatile("ds_read_b128 %0, %1" : "=v"(DST[t][0]) : "v"(bufa + off));                   \
-                asm volatile("ds_read_b128 %0, %1" : "=v"(DST[t][1]) : "v"(bufa + (off ^ 64u)));           \
+        // Two fragments (f, f + 2) per iteration, one register set each: while one fragment's 12 MFMAs of a filter row
+        // run, the other fragment's reads of that row and this fragment's reads of the next row are in flight (counted
+        // lgkmcnt: the 6 newest reads may still be outstanding), and four accumulator chains keep the matrix pipe fed.
+        for (int f0 = fg; f0 < a.nfr; f0 += 4) {
+            f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+            int ohl[2], ow[2];
+            bool inside[2];
+            unsigned ad[2][3][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int f = f0 + 2 * u;
+                inside[u] = f < a.nfr;                               // odd tail: the second slot repeats the first (not stored)
+                if (!inside[u]) f = f0;
+                const int l0 = 16 * f;
+                const int ohl0 = l0 / W;                             // wave-uniform
+                ow[u] = l0 - ohl0 * W + i16;
+                ohl[u] = ohl0;
+                if (ow[u] >= W) { ow[u] -= W; ++ohl[u]; }            // W >= 16: a fragment spans at most two rows
+                if (ohl[u] >= a.R) { inside[u] = false; ohl[u] = a.R - 1; }      // the last fragment may run past the strip
+                // The row pitch P is a multiple of 8 slots, so the swizzle key (position & 7) is the slot's (ow + s) & 7
+                // whatever the filter row: three addresses per K half (s = 0, 1, 2), the filter row r is the IMMEDIATE offset
+                // r * P * 128 of the read (the first version computed all 18 addresses: 5.8 VALU instructions per MFMA)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int slot = ow[u] + s;
+                    const unsigned off = (unsigned)((ohl[u] * P + slot) * 128 + ((qd ^ (slot & 7)) << 4));
+                    ad[u][s][0] = bufa + off;
+                    ad[u][s][1] = bufa + (off ^ 64u);
+                }
             }
-#define C3_MFMA(SRC, T0)                                                                                  \
+            // (inline asm: every register an asm read writes stays live until its wait; a set is reloaded only after the
+            // MFMAs that read it have all been ISSUED -- they fetch their operands in their first passes, an LDS read
+            // returns 64+ cycles later)
+            c3_s16x8 fa[3][2], fb[3][2];
+#define C3_READ(DST, U_, R_)                                                                              \
+            _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                \
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[s][0]) : "v"(ad[U_][s][0]), "n"((R_) * PB)); \
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST[s][1]) : "v"(ad[U_][s][1]), "n"((R_) * PB)); \
+            }
+#define C3_MFMA(SRC, U_, R_)                                                                              \
             _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                  \
                 _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                           \
                     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[T0 + t][kh][j], SRC[t][kh], acc[j], 0, 0, 0);
-#define C3_WAIT()                                                                                         \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+                        acc[U_][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[3 * (R_) + t][kh][j], SRC[t][kh], acc[U_][j], 0, 0, 0);
+#define C3_WAIT(N_)                                                                                       \
+            asm volatile("s_waitcnt lgkmcnt(" #N_ ")" ::: "memory");                                       \
             __builtin_amdgcn_sched_barrier(0);
-            C3_READ(fa, 0)
-            C3_WAIT()
-            C3_READ(fb, 3)
+            C3_READ(fa, 0, 0)
+            C3_READ(fb, 1, 0)
+            C3_WAIT(6)
+            C3_MFMA(fa, 0, 0)
             __builtin_amdgcn_sched_barrier(0);
-            C3_MFMA(fa, 0)
-            C3_WAIT()
-            C3_READ(fa, 6)
+            C3_READ(fa, 0, 1)
+            C3_WAIT(6)
+            C3_MFMA(fb, 1, 0)
             __builtin_amdgcn_sched_barrier(0);
-            C3_MFMA(fb, 3)
-            C3_WAIT()
-            C3_MFMA(fa, 6)
+            C3_READ(fb, 1, 1)
+            C3_WAIT(6)
+            C3_MFMA(fa, 0, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_READ(fa, 0, 2)
+            C3_WAIT(6)
+            C3_MFMA(fb, 1, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            C3_READ(fb, 1, 2)
+            C3_WAIT(6)
+            C3_MFMA(fa, 0, 2)
+            C3_WAIT(0)
+            C3_MFMA(fb, 1, 2)
 #undef C3_READ
 #undef C3_MFMA
 #undef C3_WAIT
-            const int oh = oh0 + ohl;
-            if (inside && oh < a.H) {
-                u32x4 o0;
-                o0[0] = pack_bf16x2(acc[0][0], acc[0][1]); o0[1] = pack_bf16x2(acc[0][2], acc[0][3]);
-                o0[2] = pack_bf16x2(acc[1][0], acc[1][1]); o0[3] = pack_bf16x2(acc[1][2], acc[1][3]);
-                unsigned short* yp = a.y + (((int64_t)n * a.H + oh) * W + ow) * C3_C + chalf * 32 + qd * 8;
-                *reinterpret_cast<u32x4*>(yp) = o0;
-                if (a.partial) {          // statistics of what the consumer reads: the rounded values
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float a0 = __uint_as_float(o0[k] << 16), a1 = __uint_as_float(o0[k] & 0xffff0000u);
-                        s1[2 * k] += a0; s2[2 * k] = fmaf(a0, a0, s2[2 * k]);
-                        s1[2 * k + 1] += a1; s2[2 * k + 1] = fmaf(a1, a1, s2[2 * k + 1]);
+            for (int u = 0; u < 2; ++u) {
+                const int oh = oh0 + ohl[u];
+                if (inside[u] && oh < a.H) {
+                    u32x4 o0;
+                    o0[0] = pack_bf16x2(acc[u][0][0], acc[u][0][1]); o0[1] = pack_bf16x2(acc[u][0][2], acc[u][0][3]);
+                    o0[2] = pack_bf16x2(acc[u][1][0], acc[u][1][1]); o0[3] = pack_bf16x2(acc[u][1][2], acc[u][1][3]);
+                    unsigned short* yp = a.y + (((int64_t)n * a.H + oh) * W + ow[u]) * C3_C + chalf * 32 + qd * 8;
+                    *reinterpret_cast<u32x4*>(yp) = o0;
+                    if (a.partial) {          // statistics of what the consumer reads: the rounded values
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float a0 = __uint_as_float(o0[k] << 16), a1 = __uint_as_float(o0[k] & 0xffff0000u);
+                            s1[2 * k] += a0; s2[2 * k] = fmaf(a0, a0, s2[2 * k]);
+                            s1[2 * k + 1] += a1; s2[2 * k + 1] = fmaf(a1, a1, s2[2 * k + 1]);
+                        }
                     }
                 }
             }
@@ -195,7 +229,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 static int c3_plan(int NB, int H, int W, C3Args* a, int* lds, int* grid) {
     if (NB < 1 || H < 1 || W < 16 || W > 1024) return -1;
-    a->NB = NB; a->H = H; a->W = W; a->P = W + 2;
+    a->NB = NB; a->H = H; a->W = W; a->P = W + 2 <= 24 ? 24 : (W + 2 <= 32 ? 32 : 64);            // the instantiated pitches
+    if (W + 2 > 64) return -1;
     static int rows = 0;
     if (rows == 0) { const char* e = getenv("DTF_C3_ROWS"); rows = e ? atoi(e) : 3; if (rows < 1 || rows > 8) rows = 3; }
     int R = rows < H ? rows : H;
@@ -251,10 +286,14 @@ int dtf_conv3x3_c64(const void* x, const void* w, const void* zero, void* y, flo
     a.y = (unsigned short*)y; a.partial = partial;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<24 * 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<32 * 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64_kernel<64 * 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         attr = true;
     }
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(grid), dim3(256), lds, stream, a);
+    if (a.P == 24) hipLaunchKernelGGL((conv3x3_c64_kernel<24 * 128>), dim3(grid), dim3(256), lds, stream, a);
+    else if (a.P == 32) hipLaunchKernelGGL((conv3x3_c64_kernel<32 * 128>), dim3(grid), dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((conv3x3_c64_kernel<64 * 128>), dim3(grid), dim3(256), lds, stream, a);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -5,7 +5,7 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 R=$PWD
 rm -rf $R/gpurun_out/prof_stem; mkdir -p $R/gpurun_out/prof_stem
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_stem -o trace -- python3 $R/scripts/stem_bench.py "$@" 2>&1 | grep -v "^[EW]2026" | tail -8 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_stem -o trace -- python3 $R/scripts/${PROF_SCRIPT:-stem_bench.py} "$@" 2>&1 | grep -v "^[EW]2026" | tail -8 || exit 1
 cd $R && python3 - <<PY
 import csv, collections, statistics
 rows = list(csv.DictReader(open("gpurun_out/prof_stem/trace_kernel_trace.csv")))

@@ -120,7 +120,7 @@ def test_stem_fused_weight_gradient_matches_unfused(dev, monkeypatch):
 # ---------------------------------------------------------------------------------------------------------------------
 # K16: direct 64 -> 64 channel 3x3 convolution (ops/csrc/conv3x3_c64_kernels.hip)
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg", [(2, 56, 56), (3, 17, 23), (1, 16, 16), (2, 9, 40), (5, 28, 28), (1, 3, 98)])
+@pytest.mark.parametrize("cfg", [(2, 56, 56), (3, 17, 23), (1, 16, 16), (2, 9, 40), (5, 28, 28), (1, 3, 62)])
 def test_conv3x3_c64_matches_reference(dev, cfg):
     """Forward + statistics epilogue vs fp32 conv2d: fragments that wrap around a row end, strips that end inside the
     image, odd widths, the smallest width."""
