@@ -1339,6 +1339,24 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
     return 0;
 }
 
+// Backward finalize only, from reduction partials the producer of dy already wrote (the K9 pool gather of ops/stem.py):
+// dgamma, dbeta and the coefficients of dx = k1 dy' + k2 x + k3.
+int dtf_bn_bwd_finalize_pre(const float* partial, int nblk, const void* gamma, int param_dtype, const float* mean,
+                            const float* invstd, void* dgamma, void* dbeta, float* coef, int64_t M, int C, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (C % 8 != 0 || M <= 0 || nblk <= 0) return -20;
+    const float inv_count = 1.0f / (float)M;
+    const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
+    if (param_dtype == DTF_BF16)
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C, inv_count, gamma,
+                           mean, invstd, dgamma, dbeta, coef);
+    else
+        hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nblk, C, inv_count, gamma,
+                           mean, invstd, dgamma, dbeta, coef);
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
 // Backward of max_pool(relu(BN(x))) (ops/pool.py bn_relu_max_pool2d): dyp / tap are the POOLED gradient
 // [N, OH, OW, C] and the pool's winning-tap bytes; see PoolGeom.
 int dtf_bn_bwd_train_pool(const void* dyp, const void* tap, const void* x, const void* gamma, int param_dtype,

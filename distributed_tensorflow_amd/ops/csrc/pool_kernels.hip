@@ -177,6 +177,115 @@ __global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const unsigned sh
     }
 }
 
+// The same gather for max_pool(relu(BN(z))) (ops/stem.py) with the BatchNorm backward REDUCTION folded in: the lane that
+// has just produced the gradient of four pixels also loads their z, applies the ReLU mask (recomputed from z, scale,
+// shift like the K7 backward) and accumulates s1 = sum g, s2 = sum g (z - mean) per channel -- the separate K7 reduction
+// pass would read the 411 MB gradient and z once more (167 us at batch 256; the extra z read here costs ~70).  g is
+// the bf16-ROUNDED gradient, i.e. exactly what the stored tensor holds.  A lane's channel group is fixed (C / 8 divides
+// the block and the grid stride), partial rows [block][2][C] in the K7 finalize layout, fixed summation order.
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s2_bnred_kernel(const unsigned short* __restrict__ dy,
+                                                                     const unsigned char* __restrict__ tap,
+                                                                     const unsigned short* __restrict__ z,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     unsigned short* __restrict__ dx, float* __restrict__ partial,
+                                                                     int N, int H, int W, int C, int OH, int OW, int pad) {
+    const int C8 = C >> 3, PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+    const int64_t total = (int64_t)N * PH * PW * C8;
+    const int c8 = threadIdx.x % C8;
+    float mu[8], sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        mu[k] = mean[c8 * 8 + k]; sc[k] = scale[c8 * 8 + k]; sh[k] = shift[c8 * 8 + k];
+        s1[k] = 0.f; s2[k] = 0.f;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t pix = t / C8;
+        const int w0 = 2 * (int)(pix % PW);
+        pix /= PW;
+        const int h0 = 2 * (int)(pix % PH);
+        const int n = (int)(pix / PH);
+        int oh_lo = h0 + pad - 2;
+        oh_lo = oh_lo <= 0 ? 0 : (oh_lo + 1) >> 1;
+        int oh_hi = (h0 + 1 + pad) >> 1;
+        if (oh_hi > OH - 1) oh_hi = OH - 1;
+        int ow_lo = w0 + pad - 2;
+        ow_lo = ow_lo <= 0 ? 0 : (ow_lo + 1) >> 1;
+        int ow_hi = (w0 + 1 + pad) >> 1;
+        if (ow_hi > OW - 1) ow_hi = OW - 1;
+        // z of the four pixels first: independent of the window loads below
+        u32x4 zr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = h0 + (q >> 1), w = w0 + (q & 1);
+            zr[q] = (u32x4){0u, 0u, 0u, 0u};
+            if (h < H && w < W) zr[q] = *reinterpret_cast<const u32x4*>(z + ((((int64_t)n * H + h) * W + w) * C) + c8 * 8);
+        }
+        float acc[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[q][k] = 0.f;
+        }
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int64_t o = DTF_IDX((((int64_t)n * OH + oh) * OW + ow) * C + c8 * 8, (int64_t)N * OH * OW * C,
+                                          "maxpool_bwd_k3s2_bnred window");
+                const u32x2 pk = *reinterpret_cast<const u32x2*>(tap + o);
+                float g[8];
+                load8<DTF_BF16>(dy, o, g);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned kh = (unsigned)(h0 + (q >> 1) + pad - 2 * oh), kw = (unsigned)(w0 + (q & 1) + pad - 2 * ow);
+                    if (kh < 3u && kw < 3u) {
+                        const unsigned me = kh * 3 + kw;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const unsigned b = (pk[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                            acc[q][k] += (b == me) ? g[k] : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int h = h0 + (q >> 1), w = w0 + (q & 1);
+            if (h < H && w < W) {
+                u32x4 r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = pack_bf16x2(acc[q][2 * k], acc[q][2 * k + 1]);
+                *reinterpret_cast<u32x4*>(dx + ((((int64_t)n * H + h) * W + w) * C) + c8 * 8) = r;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float z0 = __uint_as_float(zr[q][k] << 16), z1 = __uint_as_float(zr[q][k] & 0xffff0000u);
+                    float g0 = __uint_as_float(r[k] << 16), g1 = __uint_as_float(r[k] & 0xffff0000u);
+                    g0 = fmaf(z0, sc[2 * k], sh[2 * k]) > 0.f ? g0 : 0.f;
+                    g1 = fmaf(z1, sc[2 * k + 1], sh[2 * k + 1]) > 0.f ? g1 : 0.f;
+                    s1[2 * k] += g0; s2[2 * k] = fmaf(g0, z0 - mu[2 * k], s2[2 * k]);
+                    s1[2 * k + 1] += g1; s2[2 * k + 1] = fmaf(g1, z1 - mu[2 * k + 1], s2[2 * k + 1]);
+                }
+            }
+        }
+    }
+    __shared__ float red[2][8 * 257];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        red[0][k * 257 + threadIdx.x] = s1[k];
+        red[1][k * 257 + threadIdx.x] = s2[k];
+    }
+    __syncthreads();
+    const int lanes = 256 / C8;                    // lanes that share a channel group: tid = c8 + C8 * j
+    for (int idx = threadIdx.x; idx < 2 * C; idx += 256) {
+        const int stat = idx >= C, c = idx - stat * C;
+        const int k = c & 7, g8 = c >> 3;
+        float sum = 0.f;
+        for (int j = 0; j < lanes; ++j) sum += red[stat][k * 257 + g8 + C8 * j];
+        partial[((int64_t)blockIdx.x * 2 + stat) * C + c] = sum;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Average pooling (Inception's 3x3/1 "pool + 1x1" branches, the aux head's 5x5/3).  Same two
 // gather shapes as above; the divisor of a window is recomputed from its coordinates.
@@ -342,6 +451,30 @@ int dtf_maxpool_bwd(const void* dy, const void* tap, void* dx, int N, int H, int
         hipLaunchKernelGGL((maxpool_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, stream, dys, ts, dxs, N, H, W, C, OH, OW, stride, pad);
     else
         return -23;
+    DTF_CHECK_LAUNCH();
+    return 0;
+}
+
+// dtf_maxpool_bwd for the 3x3 / 2 pool of relu(BN(z)) with the BatchNorm backward reduction folded in; partial: fp32
+// [dtf_maxpool_bwd_bnred_blocks][2][C] (the K7 backward finalize's input); C a divisor of 2048 with C / 8 dividing 256
+int64_t dtf_maxpool_bwd_bnred_blocks(int N, int H, int W, int C) {
+    const int64_t patches = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8);
+    int64_t pb = (patches + 255) / 256;
+    if (pb > 2048) pb = 2048;
+    return pb < 1 ? 1 : pb;
+}
+
+int dtf_maxpool_bwd_bnred(const void* dy, const void* tap, const void* z, const float* mean, const float* scale,
+                          const float* shift, void* dx, float* partial, int N, int H, int W, int C, int OH, int OW, int k,
+                          int stride, int pad, hipStream_t stream) {
+    DTF_CLEAR_ERRORS();
+    if (k != 3 || stride != 2 || C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0 || N <= 0 || OH <= 0 || OW <= 0 || pad < 0 || pad >= k)
+        return -20;
+    if (OH != (H + 2 * pad - k) / stride + 1 || OW != (W + 2 * pad - k) / stride + 1) return -21;
+    const unsigned pb = (unsigned)dtf_maxpool_bwd_bnred_blocks(N, H, W, C);
+    hipLaunchKernelGGL(maxpool_bwd_k3s2_bnred_kernel, dim3(pb), dim3(256), 0, stream, (const unsigned short*)dy,
+                       (const unsigned char*)tap, (const unsigned short*)z, mean, scale, shift, (unsigned short*)dx, partial, N, H,
+                       W, C, OH, OW, pad);
     DTF_CHECK_LAUNCH();
     return 0;
 }

@@ -23,6 +23,10 @@ from . import hip
 
 _ENABLED = os.environ.get("DTF_STEM_KERNEL", "1") != "0"         # A/B switch
 _WRW = os.environ.get("DTF_STEM_WRW", "1") != "0"                # A/B switch: 0 = BatchNorm apply pass + library weight gradient
+# 1: the pool gather also reduces for the BatchNorm backward.  Measured (batch 256): the fused kernel takes 242 us against
+# 120 (gather) + 169 (K7 reduction) standalone, but the ResNet-50 step gets SLOWER with it (12 485 -> 12 275 images/s: the
+# grid-strided gather streams worse than the flat passes next to the other kernels).  Off by default.
+_POOL_RED = os.environ.get("DTF_STEM_POOL_REDUCE", "0") != "0"
 _declared = False
 
 
@@ -36,6 +40,9 @@ def _lib():
         hip.declare("dtf_stem_pack_w", [P, P, P])
         hip.declare("dtf_stem_fwd", [P, P, P, P, P, I, I, I, P])
         hip.declare("dtf_bn_finalize_pre", [P, P, I, P, P, Fl, Fl, P, P, P, P, P, I, L, I, P])
+        hip.declare("dtf_bn_bwd_finalize_pre", [P, I, P, I, P, P, P, P, P, L, I, P])
+        hip.declare("dtf_maxpool_bwd_bnred_blocks", [I, I, I, I], L)
+        hip.declare("dtf_maxpool_bwd_bnred", [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P])
         if hasattr(lib, "dtf_stem_wrw"):
             hip.declare("dtf_stem_wrw_ok", [I, I, I], I)
             hip.declare("dtf_stem_wrw_workspace", [I, I, I], L)
@@ -121,19 +128,31 @@ class _StemFn(torch.autograd.Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         M = N * H * W
         dbn = torch.empty((N, C, H, W), dtype=dy.dtype, device=dev, memory_format=torch.channels_last)
-        rc = poolmod._lib().dtf_maxpool_bwd(hip.ptr(dy), hip.ptr(tap), hip.ptr(dbn), N, H, W, C, OH, OW, k, stride, pad,
-                                            hip.stream())
-        hip.check(rc, "dtf_maxpool_bwd")
         dgb = torch.empty(2, C, dtype=gamma.dtype, device=dev)
         coef = torch.empty(3, C, dtype=torch.float32, device=dev)
         fused = bool(_WRW and hasattr(lib, "dtf_stem_wrw") and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
                      and lib.dtf_stem_wrw_ok(N, x.shape[2], x.shape[3]))
         dc = None if fused else torch.empty((N, C, H, W), dtype=dy.dtype, device=dev, memory_format=torch.channels_last)
-        rc = bnmod._lib().dtf_bn_bwd_train(
-            hip.ptr(dbn), hip.ptr(c), None, hip.ptr(gamma), hip.dt(gamma), stats[0].data_ptr(), stats[1].data_ptr(),
-            stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dc) if dc is not None else None, None, dgb[0].data_ptr(),
-            dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(bnmod._partial(dev, M, C)), M, C, 1, 0, 0, 0, hip.stream())
-        hip.check(rc, "dtf_bn_bwd_train (stem)")
+        if fused and _POOL_RED and k == 3 and stride == 2 and 256 % (C // 8) == 0:
+            # the pool gather also reduces for the BatchNorm backward (no separate pass over its 411 MB output and z)
+            part = torch.empty(int(lib.dtf_maxpool_bwd_bnred_blocks(N, H, W, C)), 2, C, dtype=torch.float32, device=dev)
+            rc = lib.dtf_maxpool_bwd_bnred(hip.ptr(dy), hip.ptr(tap), hip.ptr(c), stats[0].data_ptr(), stats[2].data_ptr(),
+                                           stats[3].data_ptr(), hip.ptr(dbn), hip.ptr(part), N, H, W, C, OH, OW, k, stride, pad,
+                                           hip.stream())
+            hip.check(rc, "dtf_maxpool_bwd_bnred")
+            rc = lib.dtf_bn_bwd_finalize_pre(hip.ptr(part), part.shape[0], hip.ptr(gamma), hip.dt(gamma), stats[0].data_ptr(),
+                                             stats[1].data_ptr(), dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), M, C,
+                                             hip.stream())
+            hip.check(rc, "dtf_bn_bwd_finalize_pre")
+        else:
+            rc = poolmod._lib().dtf_maxpool_bwd(hip.ptr(dy), hip.ptr(tap), hip.ptr(dbn), N, H, W, C, OH, OW, k, stride, pad,
+                                                hip.stream())
+            hip.check(rc, "dtf_maxpool_bwd")
+            rc = bnmod._lib().dtf_bn_bwd_train(
+                hip.ptr(dbn), hip.ptr(c), None, hip.ptr(gamma), hip.dt(gamma), stats[0].data_ptr(), stats[1].data_ptr(),
+                stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dc), None, dgb[0].data_ptr(),
+                dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(bnmod._partial(dev, M, C)), M, C, 1, 0, 0, 0, hip.stream())
+            hip.check(rc, "dtf_bn_bwd_train (stem)")
         dw = None
         if ctx.needs_input_grad[1]:
             if fused:

@@ -169,3 +169,29 @@ def test_conv3x3_c64_module_forward_backward(dev):
 
     assert rel(x.grad, x2.grad) < 3e-2
     assert rel(m.weight.grad, w2.grad) < 3e-2
+
+
+def test_stem_pool_gather_with_bn_reduction_matches_separate_pass(dev, monkeypatch):
+    """The K9 pool gather that also reduces for the BatchNorm backward vs pool gather + K7 reduction pass: same values
+    summed in another order (gamma / beta / filter gradients to fp32 round-off of the partial sums)."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, stem
+
+    if not hasattr(stem._lib(), "dtf_stem_wrw"):
+        pytest.skip("fused weight gradient not built")
+    x, w = _inputs(dev, 5, 70, 96, seed=3)
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    bn = bnmod.FusedBatchNormAct(64, relu=True).to(dev).to(torch.bfloat16).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    out = []
+    for fused in (True, False):
+        monkeypatch.setattr(stem, "_POOL_RED", fused)
+        for p in (conv.weight, bn.weight, bn.bias):
+            p.grad = None
+        y = stem.stem_conv_bn_relu_pool(x, conv, bn, 3, 2, 1)
+        torch.manual_seed(5)
+        y.backward(torch.randn_like(y))
+        out.append([p.grad.float().clone() for p in (conv.weight, bn.weight, bn.bias)])
+    for a, b in zip(*out):
+        assert float((a - b).norm() / b.norm()) < 1e-2
