@@ -388,6 +388,8 @@ def _wrw_lib():
         hip.declare("dtf_conv_wrw_direct_ok", [I, I, I, I, I, I, I, I, I, I])
         hip.declare("dtf_conv_wrw_direct_workspace", [I, I, I, I, I], L)
         hip.declare("dtf_conv_wrw_direct", [P, P, P, I, P, P, I, I, I, I, I, P])
+        hip.declare("dtf_conv_wrw_direct_workspace2", [I, I, I, I, I, I], L)
+        hip.declare("dtf_conv_wrw_direct2", [P, P, P, I, P, P, I, I, I, I, I, I, P])
         _wrw_declared = True
     return lib
 
@@ -412,11 +414,12 @@ def conv_wrw_direct_ok(x, weight, stride, padding):
     if not (_CONV_WRW_DIRECT and _CONV_WRW and x.is_cuda):
         return False
     cout, cin, kh, kw = weight.shape
-    if (kh, kw) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) != (1, 1) or cin % 32 or cout % 32:
+    if (kh, kw) != (3, 3) or tuple(stride) != (1, 1) or tuple(padding) not in ((1, 1), (0, 0)) or cin % 32 or cout % 32:
         return False
     if max(cin, cout) > _CONV_WRW_DIRECT_MAX_CH or x.shape[1] != cin:
         return False
-    return bool(_wrw_lib().dtf_conv_wrw_direct_ok(x.shape[0], x.shape[2], x.shape[3], cin, cout, kh, kw, 1, 1, 1))
+    p = int(padding[0])
+    return bool(_wrw_lib().dtf_conv_wrw_direct_ok(x.shape[0], x.shape[2], x.shape[3], cin, cout, kh, kw, 1, p, p))
 
 
 def conv_wrw_profitable(weight, x=None, stride=(1, 1), padding=(1, 1)):
@@ -438,7 +441,8 @@ def conv_wrw(dy, x, weight, stride, padding):
     KH, KW = weight.shape[2], weight.shape[3]
     dev = x.device
     if conv_wrw_direct_ok(x, weight, stride, padding):
-        n = int(lib.dtf_conv_wrw_direct_workspace(NB, H, W, Cin, Cout))
+        pad = int(padding[0])
+        n = int(lib.dtf_conv_wrw_direct_workspace2(NB, H, W, Cin, Cout, pad))
         ws = _wrw_ws.get(dev)
         if ws is None or ws.numel() < n:
             ws = torch.empty(max(n, 1 << 22), dtype=torch.float32, device=dev)
@@ -448,8 +452,8 @@ def conv_wrw(dy, x, weight, stride, padding):
             z = torch.zeros(64, dtype=torch.bfloat16, device=dev)
             _zero_page[dev] = z
         dw = torch.empty((Cout, KH, KW, Cin), dtype=torch.bfloat16, device=dev)
-        rc = lib.dtf_conv_wrw_direct(hip.ptr(dy), hip.ptr(x), hip.ptr(dw), hip.dt(dw), hip.ptr(ws), hip.ptr(z), NB, H, W,
-                                     Cin, Cout, hip.stream())
+        rc = lib.dtf_conv_wrw_direct2(hip.ptr(dy), hip.ptr(x), hip.ptr(dw), hip.dt(dw), hip.ptr(ws), hip.ptr(z), NB, H, W,
+                                      Cin, Cout, pad, hip.stream())
         hip.check(rc, "dtf_conv_wrw_direct")
         return dw.permute(0, 3, 1, 2)
     n = int(lib.dtf_conv_wrw_workspace(NB * OH * OW, Cout, KH * KW * Cin))

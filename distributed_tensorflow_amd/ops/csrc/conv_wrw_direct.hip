@@ -7,7 +7,7 @@
 // per filter tap; on a 64-channel layer that is 32 KB through the per-CU load path for 8 MFMAs per wave and K step,
 // and the load path, not HBM or the matrix pipe, is the limit (docs/STATUS.md).  Here every pixel is staged ONCE:
 //
-//   * a block owns strips of R = 4 output rows of one image.  The strip's R dY rows and R + 2 input rows go into LDS as
+//   * a block owns strips of R output rows of one image (R = 4, fewer where a strip would not fit LDS).  The strip's R dY rows and R + 2 input rows go into LDS as
 //     FLATTENED position lists with a row pitch of P = W + 2: the two extra columns hold the convolution's zero padding
 //     (X) / zeros (dY).  A filter tap (r, s) is then a UNIFORM shift of the flattened index, q = p + r P + s - 1, and
 //     the products that wrap around a row end vanish because dY is zero there -- no per-pixel masks anywhere;
@@ -32,7 +32,8 @@ typedef const __attribute__((address_space(1))) void wd_glb_void;
 
 struct WdArgs {
     const unsigned short* dy; const unsigned short* x; const unsigned short* zero; float* slab;
-    int NB, H, W, P, nch, xpos, ypos, nstrips, strips_per_img, npw;      // npw: pieces per wave (uniform)
+    int NB, H, W, P, nch, xpos, ypos, nstrips, strips_per_img, npw;      // npw: pieces per wave (uniform); H, W: OUTPUT size
+    int R, Hx, Wx, pad;                                                  // rows per strip; input size; padding (0 / 1)
     int Cin, Cout, nsl_ci, nsl, bps;                                     // channel slices; bps: blocks per slice
 };
 
@@ -80,12 +81,15 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
         const bool isx = j < nxp;
         const int pos = (isx ? j : j - nxp) * 8 + (lane >> 3);      // LDS position inside its image
         const int q = isx ? pos - 1 : pos;                          // X image has one position of front slack
-        const int rows = isx ? WD_R + 2 : WD_R;
+        const int rows = isx ? a.R + 2 : a.R;
         int off = -1, rl = 0;
         if (q >= 0 && q < rows * P) {
             rl = q / P;
             const int col = q - rl * P;
-            if (col >= 1 && col <= W) off = rl * W + col - 1;
+            // dY: columns 1 .. W are the row, 0 and W + 1 zeros.  X: column c is input column c - pad (padding 1: the two
+            // outer columns are the convolution's zero padding; padding 0: all W + 2 columns are image)
+            if (isx) { if ((unsigned)(col - a.pad) < (unsigned)a.Wx) off = rl * a.Wx + col - a.pad; }
+            else if (col >= 1 && col <= W) off = rl * W + col - 1;
         }
         const int d16 = lane & 7;
         const int c = (d16 >> 1) ^ wd_swz(pos);                     // source 32-byte chunk that lands in this slot
@@ -97,8 +101,8 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
         pc_lds[k] = (isx ? 0 : ybase) + (isx ? j : j - nxp) * 1024;
     }
     auto stage = [&](int strip, int buf) {
-        const int n = strip / a.strips_per_img, h0 = (strip - n * a.strips_per_img) * WD_R;
-        const unsigned short* xw = a.x + ((int64_t)n * H + (h0 - 1)) * W * a.Cin;     // window origin: row h0 - 1
+        const int n = strip / a.strips_per_img, h0 = (strip - n * a.strips_per_img) * a.R;
+        const unsigned short* xw = a.x + ((int64_t)n * a.Hx + (h0 - a.pad)) * a.Wx * a.Cin;     // window origin: input row h0 - pad
         const unsigned short* yw = a.dy + ((int64_t)n * H + h0) * W * a.Cout;
         unsigned char* base = smem + buf * bufbytes;
 #pragma unroll
@@ -106,9 +110,9 @@ __global__ __launch_bounds__(512) void conv_wrw_direct_kernel(WdArgs a) {
             if (k < a.npw) {
                 const bool isx = pc_row[k] < 256;
                 const int rl = pc_row[k] & 255;
-                const int ih = isx ? h0 - 1 + rl : h0 + rl;
+                const int ih = isx ? h0 - a.pad + rl : h0 + rl;
                 const unsigned short* src = (isx ? xw : yw) + pc_off[k];
-                if (pc_off[k] < 0 || (unsigned)ih >= (unsigned)H) src = a.zero;
+                if (pc_off[k] < 0 || (unsigned)ih >= (unsigned)(isx ? a.Hx : H)) src = a.zero;
                 __builtin_amdgcn_global_load_lds((wd_glb_void*)src, (wd_lds_void*)(base + pc_lds[k]), 16, 0, 0);
             }
         }
@@ -261,20 +265,24 @@ __global__ __launch_bounds__(256) void wd_reduce_kernel(const float* __restrict_
     }
 }
 
-static int wd_plan(int NB, int H, int W, int Cin, int Cout, WdArgs* a, int* grid) {
-    if (Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32 || Cin > 256 || Cout > 256) return -1;
+// H, W: OUTPUT size; pad 1 ('same': input H x W) or 0 ('valid': input (H + 2) x (W + 2))
+static int wd_plan(int NB, int H, int W, int Cin, int Cout, int pad, WdArgs* a, int* grid) {
+    if (Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32 || Cin > 256 || Cout > 256 || (pad != 0 && pad != 1)) return -1;
     const int P = W + 2;
-    const int nch = (WD_R * P + 31) / 32;
-    const int xpos = (1 + nch * 32 + 2 * P + 2 + 7) / 8 * 8;      // largest read: position nch*32 - 1 shifted by 2 P + 1 (+ slack)
-    const int ypos = nch * 32;
-    if (2 * (xpos + ypos) * 128 > 163840) return -1;               // two buffers must fit the 160 KB of LDS
-    if (xpos < 1 + (WD_R + 2) * P) return -1;
-    const int npieces = (xpos + ypos) / 8;
-    const int npw = (npieces + 7) / 8;
-    if (nch > 8) return -1;                                        // the unrolled chunk loop
-    if (npw > WD_MAXP || npw < 1) return -1;                       // the counted vmcnt cases of the kernel
+    // rows per strip: the most (<= WD_R) whose two buffers fit the 160 KB of LDS and whose chunk / piece counts fit the
+    // unrolled loops (wide images -- Inception's 147 x 147 stem layers -- run one row per strip)
+    int R = WD_R < H ? WD_R : H, nch = 0, xpos = 0, ypos = 0, npw = 0;
+    for (;; --R) {
+        if (R < 1) return -1;
+        nch = (R * P + 31) / 32;
+        xpos = (1 + nch * 32 + 2 * P + 2 + 7) / 8 * 8;      // largest read: position nch*32 - 1 shifted by 2 P + 1 (+ slack)
+        ypos = nch * 32;
+        npw = ((xpos + ypos) / 8 + 7) / 8;
+        if (2 * (xpos + ypos) * 128 <= 163840 && xpos >= 1 + (R + 2) * P && nch <= 8 && npw <= WD_MAXP && npw >= 1) break;
+    }
     a->NB = NB; a->H = H; a->W = W; a->P = P; a->nch = nch; a->xpos = xpos; a->ypos = ypos; a->npw = npw;
-    a->strips_per_img = (H + WD_R - 1) / WD_R;
+    a->R = R; a->pad = pad; a->Hx = H + 2 - 2 * pad; a->Wx = W + 2 - 2 * pad;
+    a->strips_per_img = (H + R - 1) / R;
     a->nstrips = NB * a->strips_per_img;
     int cu = 0, dev = 0;
     (void)hipGetDevice(&dev);
@@ -290,29 +298,36 @@ static int wd_plan(int NB, int H, int W, int Cin, int Cout, WdArgs* a, int* grid
 
 extern "C" {
 
-// 1 when the direct kernel covers this geometry (3x3, stride 1, padding 1, 64 -> 64 channels, strip fits LDS)
+// 1 when the direct kernel covers this geometry (3x3, stride 1, padding 1 or 0, channels in multiples of 32 up to 256, a
+// strip fits LDS); H, W: INPUT size
 int dtf_conv_wrw_direct_ok(int NB, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int ph, int pw) {
-    if (KH != 3 || KW != 3 || stride != 1 || ph != 1 || pw != 1 || NB < 1 || H < 1 || W < 1) return 0;
+    if (KH != 3 || KW != 3 || stride != 1 || ph != pw || (ph != 0 && ph != 1) || NB < 1) return 0;
+    const int OH = H - 2 + 2 * ph, OW = W - 2 + 2 * ph;
+    if (OH < 1 || OW < 1) return 0;
     WdArgs a{};
     int grid;
-    return wd_plan(NB, H, W, Cin, Cout, &a, &grid) == 0;
+    return wd_plan(NB, OH, OW, Cin, Cout, ph, &a, &grid) == 0;
 }
 
-// fp32 workspace floats: one slab per block
-int64_t dtf_conv_wrw_direct_workspace(int NB, int H, int W, int Cin, int Cout) {
+// fp32 workspace floats: one slab per block (H, W: INPUT size)
+int64_t dtf_conv_wrw_direct_workspace2(int NB, int H, int W, int Cin, int Cout, int pad) {
     WdArgs a{};
     int grid = 0;
-    if (wd_plan(NB, H, W, Cin, Cout, &a, &grid) != 0) return 0;
+    if (wd_plan(NB, H - 2 + 2 * pad, W - 2 + 2 * pad, Cin, Cout, pad, &a, &grid) != 0) return 0;
     return (int64_t)grid * 9 * WD_C * WD_C;
 }
+int64_t dtf_conv_wrw_direct_workspace(int NB, int H, int W, int Cin, int Cout) {
+    return dtf_conv_wrw_direct_workspace2(NB, H, W, Cin, Cout, 1);
+}
 
-// dw[Cout][3][3][Cin] (out_dtype: bf16 / fp32) from dy[NB, H, W, Cout] and x[NB, H, W, Cin]; zero: >= 16 bytes of zeros
-int dtf_conv_wrw_direct(const void* dy, const void* x, void* dw, int out_dtype, float* workspace, const void* zero, int NB, int H,
-                        int W, int Cin, int Cout, hipStream_t stream) {
+// dw[Cout][3][3][Cin] (out_dtype: bf16 / fp32) from dy[NB, OH, OW, Cout] and x[NB, H, W, Cin] (OH = H - 2 + 2 pad);
+// zero: >= 16 bytes of zeros
+int dtf_conv_wrw_direct2(const void* dy, const void* x, void* dw, int out_dtype, float* workspace, const void* zero, int NB,
+                         int H, int W, int Cin, int Cout, int pad, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     WdArgs a{};
     int grid = 0;
-    if (wd_plan(NB, H, W, Cin, Cout, &a, &grid) != 0) return -80;
+    if (wd_plan(NB, H - 2 + 2 * pad, W - 2 + 2 * pad, Cin, Cout, pad, &a, &grid) != 0) return -80;
     if ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw) | ((uintptr_t)workspace) | ((uintptr_t)zero)) & 15) return -16;
     a.dy = (const unsigned short*)dy; a.x = (const unsigned short*)x; a.zero = (const unsigned short*)zero; a.slab = workspace;
     const int lds = 2 * (a.xpos + a.ypos) * 128;
@@ -327,6 +342,11 @@ int dtf_conv_wrw_direct(const void* dy, const void* x, void* dw, int out_dtype, 
                        Cin, Cout, a.nsl_ci);
     DTF_CHECK_LAUNCH();
     return 0;
+}
+
+int dtf_conv_wrw_direct(const void* dy, const void* x, void* dw, int out_dtype, float* workspace, const void* zero, int NB, int H,
+                        int W, int Cin, int Cout, hipStream_t stream) {
+    return dtf_conv_wrw_direct2(dy, x, dw, out_dtype, workspace, zero, NB, H, W, Cin, Cout, 1, stream);
 }
 
 }  // extern "C"

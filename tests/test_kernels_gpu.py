@@ -1447,8 +1447,8 @@ def test_conv_wrw_direct_kernel_matches_reference(dev, shape, monkeypatch):
     y2.backward(dy.float())
     ref = w2.grad
     assert conv.conv_wrw_direct_ok(x, w, (1, 1), (1, 1))
-    wide = torch.empty(1, Cin, 4, 100, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    assert not conv.conv_wrw_direct_ok(wide, w, (1, 1), (1, 1))          # two strips of a 100-pixel row do not fit the LDS
+    wide = torch.empty(1, Cin, 4, 200, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert not conv.conv_wrw_direct_ok(wide, w, (1, 1), (1, 1))          # two one-row strips of a 200-pixel row do not fit the LDS
     dw = conv.conv_wrw(dy, x, w, (1, 1), (1, 1))
     assert dw.shape == w.shape and dw.is_contiguous(memory_format=torch.channels_last)
     assert float((dw.float() - ref).norm() / ref.norm()) < 1e-2
@@ -1467,3 +1467,26 @@ def test_conv_wrw_direct_kernel_matches_reference(dev, shape, monkeypatch):
     assert "ConvFn" in type(y3.grad_fn).__name__
     y3.backward(dy)
     assert float((m.weight.grad.float() - ref).norm() / ref.norm()) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 100, 64, 64, 1), (2, 9, 147, 32, 64, 1), (2, 11, 149, 32, 32, 0), (3, 20, 37, 64, 96, 0),
+                                   (2, 6, 58, 128, 64, 0)])
+def test_conv_wrw_direct_wide_rows_and_valid_padding(dev, shape):
+    """K14 with fewer rows per strip (rows too wide for four: Inception's 147 x 147 stem layers run one row per strip)
+    and with padding 0 (the padding columns of the LDS row pitch then hold image columns) against fp32 autograd."""
+    from distributed_tensorflow_amd.ops import conv
+
+    NB, H, W, Cin, Cout, pad = shape
+    torch.manual_seed(0)
+    x = torch.randn(NB, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w2 = w.float().requires_grad_()
+    y2 = torch.nn.functional.conv2d(x.float(), w2, None, 1, pad)
+    dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y2.backward(dy.float())
+    ref = w2.grad
+    assert conv.conv_wrw_direct_ok(x, w, (1, 1), (pad, pad))
+    dw = conv.conv_wrw(dy, x, w, (1, 1), (pad, pad))
+    assert dw.shape == w.shape and dw.is_contiguous(memory_format=torch.channels_last)
+    assert float((dw.float() - ref).norm() / ref.norm()) < 1e-2
+    assert torch.equal(conv.conv_wrw(dy, x, w, (1, 1), (pad, pad)), dw)
