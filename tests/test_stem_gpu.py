@@ -195,3 +195,17 @@ def test_stem_pool_gather_with_bn_reduction_matches_separate_pass(dev, monkeypat
         out.append([p.grad.float().clone() for p in (conv.weight, bn.weight, bn.bias)])
     for a, b in zip(*out):
         assert float((a - b).norm() / b.norm()) < 1e-2
+
+
+def test_shipped_gemm_solutions_are_numerically_right(dev):
+    """Every recorded library GEMM solution (gemm_db/) against fp32 on NaN-poisoned memory (scripts/validate_gemms.py, own
+    process: TunableOp is configured before torch is imported).  One recorded solution (the 64 -> 256 channel 1x1 forward
+    product at batch 256) returned non-finite values, which BatchNorm + ReLU then silently turned into zeros."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "validate_gemms.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
