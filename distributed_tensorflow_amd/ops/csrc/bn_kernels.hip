@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_kernel(const unsigned short*
                 if (RES) o += rv[u][k];
                 if (RELU) {
                     m |= (o > 0.f ? 1u : 0u) << k;
-                    o = fmaxf(o, 0.f);
+                    o = relu_nan(o);
                 }
                 xv[u][k] = o;
             }
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(256) void bn_fwd_apply_flat_kernel(const unsigned s
             if (RES) o += g[k];
             if (RELU) {
                 m |= (o > 0.f ? 1u : 0u) << k;
-                o = fmaxf(o, 0.f);
+                o = relu_nan(o);
             }
             f[k] = o;
         }
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void bn2_fwd_apply_kernel(const unsigned short
             for (int k = 0; k < 8; ++k) {
                 float o = fmaf(av[u][k], sa[k], fmaf(bv[u][k], sb[k], ha[k]));
                 m |= (o > 0.f ? 1u : 0u) << k;
-                av[u][k] = fmaxf(o, 0.f);
+                av[u][k] = relu_nan(o);
             }
             st8bf(y + row * C + c0, av[u]);
             mrow[row * 8] = (unsigned char)m;
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void bn2_fwd_apply_flat_kernel(const unsigned 
         for (int k = 0; k < 8; ++k) {
             float o = fmaf(av[k], sa[k], fmaf(bv[k], sb[k], ha[k]));
             m |= (o > 0.f ? 1u : 0u) << k;
-            av[k] = fmaxf(o, 0.f);
+            av[k] = relu_nan(o);
         }
         stv<NTS>(reinterpret_cast<u32x4*>(y + row * C + c0), pack8(av));
         mask[DTF_IDX(((int64_t)(c0 >> 6) * M + row) * 8 + ((c0 & 63) >> 3), dtf_mask_bytes_dev(M, C), "bn2 flat mask")] = (unsigned char)m;

@@ -103,6 +103,10 @@ __device__ __forceinline__ void store1(void* base, int64_t i, float v) {
     else reinterpret_cast<float*>(base)[i] = v;
 }
 
+// ReLU that PROPAGATES NaN like the framework's (fmaxf(NaN, 0) is 0: a non-finite activation would silently become a
+// dead unit -- that is how a library GEMM solution that returned NaN went unnoticed: the loss stayed finite)
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -96,7 +96,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
 __device__ __forceinline__ float k6_act(float x, int act) {
-    if (act == ACT_RELU) return fmaxf(x, 0.f);
+    if (act == ACT_RELU) return relu_nan(x);
     if (act == ACT_GELU) return gelu_erf(x);
     if (act == ACT_GELU_TANH) return gelu_tanh_fwd(x);
     return x;

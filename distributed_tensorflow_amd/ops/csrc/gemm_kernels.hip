@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(GemmArgs a) {
             if (a.preact) store8<DTF_BF16>(a.preact, o, v);
             if (a.act == ACT_RELU) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+                for (int k = 0; k < 8; ++k) v[k] = relu_nan(v[k]);
             } else if (a.act == ACT_GELU) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(GemmArgs a) {
                 float x = v[k];
                 if (a.bias) x += (a.bias_dtype == DTF_BF16) ? load1<DTF_BF16>(a.bias, gn + k) : load1<DTF_F32>(a.bias, gn + k);
                 if (a.preact) a.preact[o + k] = f32_to_bf16(x);
-                if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
+                if (a.act == ACT_RELU) x = relu_nan(x);
                 else if (a.act == ACT_GELU) x = gelu_erf(x);
                 else if (a.act == ACT_GELU_TANH) x = gelu_tanh_fwd(x);
                 if (a.residual) x += bf16_to_f32(a.residual[o + k]);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const unsigned short* __re
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float lo = __uint_as_float(a[u][k] << 16), hi = __uint_as_float(a[u][k] & 0xffff0000u);
-            if (act == ACT_RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+            if (act == ACT_RELU) { lo = relu_nan(lo); hi = relu_nan(hi); }
             else if (act == ACT_GELU) { lo = gelu_erf(lo); hi = gelu_erf(hi); }
             else if (act == ACT_GELU_TANH) { lo = gelu_tanh_fwd(lo); hi = gelu_tanh_fwd(hi); }
             o[k] = pack_bf16x2(lo, hi);

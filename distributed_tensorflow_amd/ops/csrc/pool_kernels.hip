@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const unsigned short* 
                 load8<DTF_BF16>(xn, DTF_IDX(((int64_t)h * W + w) * C, (int64_t)H * W * C, "maxpool_fwd window"), v);
                 if (AFFINE) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f)));
+                    for (int k = 0; k < 8; ++k) v[k] = bf16_to_f32(f32_to_bf16(relu_nan(fmaf(v[k], sc[k], sh[k]))));
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
