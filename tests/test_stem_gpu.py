@@ -209,3 +209,23 @@ def test_shipped_gemm_solutions_are_numerically_right(dev):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "validate_gemms.py")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_bench_network_trains_at_the_bench_batch_size(dev):
+    """bench.py's own loop (ResNet-50, batch 256, ShardedPS, the shipped MIOpen / GEMM solution files) for ten steps: every
+    gradient and parameter finite, and the loss on the fixed batch falls.  The whole-model tests run at batch sizes whose
+    library kernels are picked by heuristics; only this one sees the tuned batch-256 solutions."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "nan_probe_ps.py"), "256", "10"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    steps = re.findall(r"step (\d+) loss ([0-9.naninf]+) non-finite gradients (\d+) .* parameters (\d+)", r.stdout)
+    assert len(steps) == 10, r.stdout[-2000:]
+    assert all(int(g) == 0 and int(p) == 0 for _, _, g, p in steps), r.stdout[-2000:]
+    losses = [float(x) for _, x, _, _ in steps]
+    assert min(losses[5:]) < losses[0] - 0.3, losses
