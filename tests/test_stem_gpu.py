@@ -229,3 +229,17 @@ def test_bench_network_trains_at_the_bench_batch_size(dev):
     assert all(int(g) == 0 and int(p) == 0 for _, _, g, p in steps), r.stdout[-2000:]
     losses = [float(x) for _, x, _, _ in steps]
     assert min(losses[5:]) < losses[0] - 0.3, losses
+
+
+def test_resnet50_layer_shapes_at_bench_batch_match_fp32(dev):
+    """Every convolution layer shape of ResNet-50 at batch 256 through the model's own routing (own kernels, tuned MIOpen
+    solvers, recorded GEMM solutions): forward, data gradient, weight gradient vs fp32 on NaN-poisoned memory
+    (scripts/validate_convs.py, own process)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "validate_convs.py"), "256"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
