@@ -339,24 +339,32 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
     // x0: row 0 of the tensor the partials were accumulated against (bn_reduce_kernel's shift), or null when the
     // partials are plain sums (K6 STATS epilogue)
     const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
+    // the per-channel operands are fetched BEFORE the reduction: after it they would be a second dependent memory round
+    // trip in a kernel that is nothing but latency (106 calls per ResNet-50 step)
+    const bool mine = threadIdx.x < BN_FIN_CH && c < C;
+    float g = 0.f, b = 0.f, rm = 0.f, rv = 0.f, xs = 0.f;
+    if (mine) {
+        g = load1<PDT>(gamma, c); b = load1<PDT>(beta, c);
+        if (running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+        if (x0) xs = bf16_to_f32(x0[c]);
+    }
     float s1, s2;
     reduce_partials8(partial, nblk, C, s1, s2);
-    if (threadIdx.x < BN_FIN_CH && c < C) {
+    if (mine) {
         const double md = (double)s1 * inv_count;
         double var = (double)s2 * inv_count - md * md;
         if (var < 0.0) var = 0.0;
-        const double m = md + (x0 ? (double)bf16_to_f32(x0[c]) : 0.0);
+        const double m = md + (double)xs;
         const float mean = (float)m;
         const float invstd = rsqrtf((float)var + eps);
-        const float g = load1<PDT>(gamma, c), b = load1<PDT>(beta, c);
         mean_out[c] = mean;
         invstd_out[c] = invstd;
         const float sc = g * invstd;
         scale_out[c] = sc;
         shift_out[c] = fmaf(-mean, sc, b);
         if (running_mean) {
-            running_mean[c] = fmaf(momentum, mean - running_mean[c], running_mean[c]);
-            running_var[c] = fmaf(momentum, (float)var * unbias - running_var[c], running_var[c]);
+            running_mean[c] = fmaf(momentum, mean - rm, rm);
+            running_var[c] = fmaf(momentum, (float)var * unbias - rv, rv);
         }
     }
 }
@@ -370,10 +378,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ invstd, void* dgamma,
                                                               void* dbeta, float* coef /* [3][C] */) {
     const int c = blockIdx.x * BN_FIN_CH + threadIdx.x;
+    const bool mine = threadIdx.x < BN_FIN_CH && c < C;
+    float is = 0.f, mu = 0.f, g = 0.f;          // fetched before the reduction (see the forward finalize)
+    if (mine) { is = invstd[c]; mu = mean[c]; g = load1<PDT>(gamma, c); }
     float s1, s2;   // s1 = sum dy', s2 = sum dy' * (x - mean)
     reduce_partials8(partial, nblk, C, s1, s2);
-    if (threadIdx.x < BN_FIN_CH && c < C) {
-        const float is = invstd[c], mu = mean[c], g = load1<PDT>(gamma, c);
+    if (mine) {
         const float dg = s2 * is;            // sum dy' * xhat
         store1<PDT>(dgamma, c, dg);
         store1<PDT>(dbeta, c, s1);
