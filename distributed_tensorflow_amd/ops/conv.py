@@ -197,8 +197,66 @@ class _Conv1x1StatsFn(torch.autograd.Function):
         return _Conv1x1Fn.backward(ctx, dy)[:2]
 
 
+# K17 (csrc/conv1x1_stats_kernels.hip): streaming 1x1 kernel with the statistics epilogue for the few-input-channel expand
+# layers (64 -> 256): replaces the library GEMM (107 us) + the K7 statistics pass over its 411 MB output (75 us)
+_K17 = os.environ.get("DTF_CONV1X1_K17", "1") != "0"
+_k17_declared = False
+
+
+class _Conv1x1K17Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        global _k17_declared
+        import ctypes
+
+        from . import hip
+
+        lib = hip.lib()
+        if not _k17_declared:
+            P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+            hip.declare("dtf_conv1x1_stats_blocks", [L, I, I], L)
+            hip.declare("dtf_conv1x1_stats", [P, P, P, P, P, L, I, I, P])
+            _k17_declared = True
+        ctx.save_for_backward(x, weight)
+        ctx.set_materialize_grads(False)
+        cout, cin = weight.shape[0], weight.shape[1]
+        N, _, H, W = x.shape
+        M = N * H * W
+        dev = x.device
+        z = _zero_page.get(dev)
+        if z is None:
+            z = torch.zeros(64, dtype=torch.bfloat16, device=dev)
+            _zero_page[dev] = z
+        y = torch.empty((N, H, W, cout), dtype=x.dtype, device=dev)
+        part = torch.empty(int(lib.dtf_conv1x1_stats_blocks(M, cin, cout)), 2, cout, dtype=torch.float32, device=dev)
+        rc = lib.dtf_conv1x1_stats(hip.ptr(x), hip.ptr(weight), hip.ptr(z), hip.ptr(y), hip.ptr(part), M, cin, cout, hip.stream())
+        hip.check(rc, "dtf_conv1x1_stats")
+        ctx.mark_non_differentiable(part)
+        return y.permute(0, 3, 1, 2), part
+
+    @staticmethod
+    def backward(ctx, dy, _dpart=None):
+        return _Conv1x1Fn.backward(ctx, dy)[:2]
+
+
+def _k17_ok(x, weight):
+    if not (_K17 and _ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.dim() == 4
+            and tuple(weight.shape[1:]) == (64, 1, 1) and weight.shape[0] == 256 and x.shape[1] == 64
+            and x.is_contiguous(memory_format=torch.channels_last) and weight.is_contiguous(memory_format=torch.channels_last)
+            and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0 and torch.is_grad_enabled()):
+        return False
+    from . import hip
+
+    lib = hip.lib()
+    if not hasattr(lib, "dtf_conv1x1_stats"):
+        return False
+    return x.shape[0] * x.shape[2] * x.shape[3] >= 65536          # a streaming kernel: large pixel counts only
+
+
 def conv1x1_stats(x, weight):
     """-> ``(conv1x1(x, weight), partials or None)``; see :class:`_Conv1x1StatsFn`."""
+    if _k17_ok(x, weight):
+        return _Conv1x1K17Fn.apply(x, weight)
     if (_STATS and _eligible(x, weight) and weight.dtype == torch.bfloat16 and weight.shape[0] >= _STATS_MIN_COUT
             and weight.shape[0] % 8 == 0 and weight.shape[1] % 32 == 0 and weight.is_contiguous(memory_format=torch.channels_last)
             and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 31) - 256):

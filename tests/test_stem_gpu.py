@@ -243,3 +243,37 @@ def test_resnet50_layer_shapes_at_bench_batch_match_fp32(dev):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "validate_convs.py"), "256"], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K17: streaming 1x1 convolution (64 -> 256 channels) with the statistics epilogue (ops/csrc/conv1x1_stats_kernels.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [(32, 56, 56), (5, 115, 114), (3, 149, 147)])
+def test_conv1x1_k17_matches_reference(dev, cfg):
+    """Forward + statistics partials vs fp32 (pixel counts that are / are not a multiple of the 128-pixel tile), then the
+    module path: Conv1x1.forward_stats -> FusedBatchNormAct(stats=...) forward and backward vs the fp32 composition."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, conv
+
+    N, H, W = cfg
+    torch.manual_seed(0)
+    x = torch.randn(N, 64, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    m = conv.Conv1x1(64, 256).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    bn = bnmod.FusedBatchNormAct(256, relu=True).to(dev).to(torch.bfloat16).train()
+    assert conv._k17_ok(x, m.weight)
+    y, part = m.forward_stats(x)
+    assert part is not None and "K17" in type(y.grad_fn).__name__
+    x2, w2 = x.detach().float().requires_grad_(), m.weight.detach().float().requires_grad_()
+    c2 = F.conv2d(x2, w2)
+    assert y.shape == c2.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert float((y.detach().float() - c2.detach()).norm() / c2.detach().norm()) < 5e-3
+    yf = y.detach().float()
+    torch.testing.assert_close(part[:, 0].sum(0), yf.sum((0, 2, 3)), rtol=1e-4, atol=5e-2)
+    torch.testing.assert_close(part[:, 1].sum(0), (yf * yf).sum((0, 2, 3)), rtol=1e-4, atol=5e-2)
+    r = bn(y, stats=part)
+    r2 = F.relu(F.batch_norm(c2, None, None, bn.weight.detach().float(), bn.bias.detach().float(), True, 0.1, bn.eps))
+    torch.testing.assert_close(r.float(), r2, rtol=3e-2, atol=3e-2)
+    g = torch.randn_like(r2)
+    r.backward(g.to(torch.bfloat16))
+    r2.backward(g.to(torch.bfloat16).float())
+    assert float((x.grad.float() - x2.grad).norm() / x2.grad.norm()) < 3e-2
+    assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 3e-2
