@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..ops.batchnorm import FusedBatchNormAct, fused_bn2_add_relu
-from ..ops.conv import Conv1x1, Conv2dTN, conv1x1, subsample_fork
+from ..ops.conv import Conv1x1, Conv2dTN, conv1x1, k17_ok, subsample_fork
 from ..ops.pool import global_avg_pool
 from ..ops.stem import stem_conv_bn_relu_pool
 
@@ -32,6 +32,14 @@ def _conv(i, o, k, stride=1):
     if k == 1 and stride == 1:
         return Conv1x1(i, o)          # NHWC 1x1 = GEMM: per-product kernel choice (ops/conv.py)
     return Conv2dTN(i, o, k, stride=stride, padding=k // 2, bias=False)   # wide layers: K6T weight gradient
+
+
+def _conv_pre(conv, x):
+    """-> ``(conv(x), statistics partials or None)``: the 64 -> 256 products of the first stage run on K17, whose
+    epilogue already holds the BatchNorm statistics."""
+    if isinstance(conv, Conv1x1) and k17_ok(x, conv.weight):
+        return conv.forward_stats(x)
+    return conv(x), None
 
 
 class Bottleneck(nn.Module):
@@ -77,9 +85,10 @@ class Bottleneck(nn.Module):
             y = self.conv1(x)
         if self.shortcut_conv is not None and self.training and x.is_cuda:
             # both BatchNorms, the add and the ReLU of a stage's first block in one K7 node
-            s = self.shortcut_conv(x)
+            s, st_s = _conv_pre(self.shortcut_conv, x)
             y = self._conv2_bn2(self.bn1(y))
-            return fused_bn2_add_relu(self.conv3(y), self.bn3, s, self.shortcut_bn)
+            y, st_y = _conv_pre(self.conv3, y)
+            return fused_bn2_add_relu(y, self.bn3, s, self.shortcut_bn, st_y, st_s)
         if self.shortcut_conv is None:
             sc = x
         elif isinstance(self.shortcut_conv, Conv1x1):

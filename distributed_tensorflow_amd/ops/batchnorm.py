@@ -32,6 +32,9 @@ def _lib():
         hip.declare("dtf_bn_fwd_train_pre", [P, P, P, P, P, P, I, P, P, Fl, Fl, P, P, P, P, P, I, L, I, I, L, P])
         hip.declare("dtf_bn2_fwd_train", [P, P, P, P, P, P, P, P, I, P, P, P, P, Fl, Fl, Fl, Fl, P, P, P, L, I, P])
         hip.declare("dtf_bn2_bwd_train", [P, P, P, P, P, P, I, P, P, P, P, P, P, P, P, L, I, P])
+        if hasattr(lib, "dtf_bn2_fwd_train_pre"):
+            hip.declare("dtf_bn2_fwd_train_pre",
+                        [P, P, P, P, P, P, P, P, I, P, P, P, P, Fl, Fl, Fl, Fl, P, P, P, L, I, P, I, P, I, P])
         hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, P, L, I, I, P])
         hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, L, L, P])
         _declared = True
@@ -192,7 +195,7 @@ class _FusedBN2AddReLU(torch.autograd.Function):
     than ``bn_a(xa, residual=bn_b(xb))`` (kernels ``bn2_*`` in ``bn_kernels.hip``)."""
 
     @staticmethod
-    def forward(ctx, xa, wa, ba, rma, rva, xb, wb, bb, rmb, rvb, mom_a, eps_a, mom_b, eps_b):
+    def forward(ctx, xa, wa, ba, rma, rva, xb, wb, bb, rmb, rvb, mom_a, eps_a, mom_b, eps_b, pre_a=None, pre_b=None):
         lib = _lib()
         M, C = _nhwc_rows(xa)
         dev = xa.device
@@ -200,11 +203,21 @@ class _FusedBN2AddReLU(torch.autograd.Function):
         stats = torch.empty(2, 4, C, dtype=torch.float32, device=dev)
         mask = torch.empty(int(lib.dtf_bn_mask_bytes(M, C)), dtype=torch.uint8, device=dev)
         part = _partial2(dev, M, C)
-        rc = lib.dtf_bn2_fwd_train(hip.ptr(xa), hip.ptr(xb), hip.ptr(y), hip.ptr(mask), hip.ptr(wa), hip.ptr(ba), hip.ptr(wb),
-                                   hip.ptr(bb), hip.dt(wa), hip.ptr(rma), hip.ptr(rva), hip.ptr(rmb), hip.ptr(rvb),
-                                   float(mom_a), float(eps_a), float(mom_b), float(eps_b), stats[0].data_ptr(),
-                                   stats[1].data_ptr(), hip.ptr(part), M, C, hip.stream())
-        hip.check(rc, "dtf_bn2_fwd_train")
+        if pre_a is not None or pre_b is not None:
+            # statistics partials [blocks][2][C] from the producing kernels' epilogues (K17): their passes are skipped
+            rc = lib.dtf_bn2_fwd_train_pre(
+                hip.ptr(xa), hip.ptr(xb), hip.ptr(y), hip.ptr(mask), hip.ptr(wa), hip.ptr(ba), hip.ptr(wb), hip.ptr(bb),
+                hip.dt(wa), hip.ptr(rma), hip.ptr(rva), hip.ptr(rmb), hip.ptr(rvb), float(mom_a), float(eps_a), float(mom_b),
+                float(eps_b), stats[0].data_ptr(), stats[1].data_ptr(), hip.ptr(part), M, C,
+                hip.ptr(pre_a) if pre_a is not None else None, pre_a.shape[0] if pre_a is not None else 0,
+                hip.ptr(pre_b) if pre_b is not None else None, pre_b.shape[0] if pre_b is not None else 0, hip.stream())
+            hip.check(rc, "dtf_bn2_fwd_train_pre")
+        else:
+            rc = lib.dtf_bn2_fwd_train(hip.ptr(xa), hip.ptr(xb), hip.ptr(y), hip.ptr(mask), hip.ptr(wa), hip.ptr(ba),
+                                       hip.ptr(wb), hip.ptr(bb), hip.dt(wa), hip.ptr(rma), hip.ptr(rva), hip.ptr(rmb),
+                                       hip.ptr(rvb), float(mom_a), float(eps_a), float(mom_b), float(eps_b),
+                                       stats[0].data_ptr(), stats[1].data_ptr(), hip.ptr(part), M, C, hip.stream())
+            hip.check(rc, "dtf_bn2_fwd_train")
         ctx.save_for_backward(xa, xb, mask, wa, wb, stats)
         ctx.dims = (M, C)
         return y
@@ -224,7 +237,7 @@ class _FusedBN2AddReLU(torch.autograd.Function):
                                    stats[0].data_ptr(), stats[1].data_ptr(), hip.ptr(dxa), hip.ptr(dxb), dgb[0].data_ptr(),
                                    dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial2(dev, M, C)), M, C, hip.stream())
         hip.check(rc, "dtf_bn2_bwd_train")
-        return dxa, dgb[0, 0], dgb[0, 1], None, None, dxb, dgb[1, 0], dgb[1, 1], None, None, None, None, None, None
+        return dxa, dgb[0, 0], dgb[0, 1], None, None, dxb, dgb[1, 0], dgb[1, 1], None, None, None, None, None, None, None, None
 
 
 _partial2_ws = {}
@@ -240,18 +253,21 @@ def _partial2(device, M, C):
     return ws
 
 
-def fused_bn2_add_relu(xa, bn_a, xb, bn_b):
+def fused_bn2_add_relu(xa, bn_a, xb, bn_b, stats_a=None, stats_b=None):
     """``relu(bn_a(xa) + bn_b(xb))`` for two :class:`FusedBatchNormAct` layers, ``bn_a`` being the one that owns the
-    add + ReLU (``relu=True``) and ``bn_b`` the plain one (``relu=False``)."""
+    add + ReLU (``relu=True``) and ``bn_b`` the plain one (``relu=False``).  ``stats_a`` / ``stats_b``: statistics
+    partials of ``xa`` / ``xb`` from their producers (``conv1x1_stats``), as for ``FusedBatchNormAct(x, stats=...)``."""
     ok = (_BN2 and bn_a.training and bn_b.training and bn_a.relu and not bn_b.relu and torch.is_grad_enabled()
           and xa.shape == xb.shape and xa.dim() == 4 and xa.dtype == xb.dtype
           and kernel_eligible(xa, bn_a.weight) and kernel_eligible(xb, bn_b.weight)
           and _nhwc_rows(xa) is not None and _nhwc_rows(xb) is not None and bn_a.weight.dtype == bn_b.weight.dtype)
     if not ok:
-        return bn_a(xa, bn_b(xb))
+        return bn_a(xa, bn_b(xb, stats=stats_b), stats=stats_a)
+    if not hasattr(_lib(), "dtf_bn2_fwd_train_pre"):
+        stats_a = stats_b = None
     return _FusedBN2AddReLU.apply(xa, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var,
                                   xb, bn_b.weight, bn_b.bias, bn_b.running_mean, bn_b.running_var,
-                                  bn_a.momentum, bn_a.eps, bn_b.momentum, bn_b.eps)
+                                  bn_a.momentum, bn_a.eps, bn_b.momentum, bn_b.eps, stats_a, stats_b)
 
 
 class _BNConcat(torch.autograd.Function):

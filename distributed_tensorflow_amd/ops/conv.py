@@ -253,6 +253,9 @@ def _k17_ok(x, weight):
     return x.shape[0] * x.shape[2] * x.shape[3] >= 65536          # a streaming kernel: large pixel counts only
 
 
+k17_ok = _k17_ok
+
+
 def conv1x1_stats(x, weight):
     """-> ``(conv1x1(x, weight), partials or None)``; see :class:`_Conv1x1StatsFn`."""
     if _k17_ok(x, weight):

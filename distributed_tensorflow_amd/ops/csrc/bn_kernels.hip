@@ -1400,20 +1400,26 @@ int dtf_bn_bwd_train_pool(const void* dyp, const void* tap, const void* x, const
 
 // relu( BN_a(xa) + BN_b(xb) ), training mode.  stats_a / stats_b: fp32 [4][C] = mean, invstd, scale, shift (outputs);
 // partial: workspace of 2 * dtf_bn_partial_floats(M, C) floats; mask: dtf_bn_mask_bytes(M, C)
-int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const void* gamma_a, const void* beta_a,
+static int bn2_fwd_train_impl(const void* xa, const void* xb, void* y, void* mask, const void* gamma_a, const void* beta_a,
                       const void* gamma_b, const void* beta_b, int param_dtype, float* rm_a, float* rv_a, float* rm_b,
                       float* rv_b, float momentum_a, float eps_a, float momentum_b, float eps_b, float* stats_a,
-                      float* stats_b, float* partial, int64_t M, int C, hipStream_t stream) {
+                      float* stats_b, float* partial, int64_t M, int C, const float* pre_a, int nblk_a, const float* pre_b,
+                      int nblk_b, hipStream_t stream) {
     DTF_CLEAR_ERRORS();
     bn_init_order();
     if (C % 8 != 0 || M <= 0 || !mask) return -20;
     int nb, rpb, ct;
     bn_grid(M, C, &nb, &rpb, &ct);
-    float* pa = partial;
-    float* pb = partial + dtf_bn_partial_floats(M, C);
+    const float* pa = partial;
+    const float* pb = partial + dtf_bn_partial_floats(M, C);
     const unsigned short *xas = (const unsigned short*)xa, *xbs = (const unsigned short*)xb;
-    const int nsa = launch_fwd_stats(xas, pa, M, C, (int64_t)C, stream);
-    const int nsb = launch_fwd_stats(xbs, pb, M, C, (int64_t)C, stream);
+    // pre_a / pre_b: statistics partials (plain sums) the producers of xa / xb already wrote (K17 epilogue): no pass over them
+    int nsa, nsb;
+    const unsigned short *x0a = xas, *x0b = xbs;          // row 0 of a tensor whose partials were accumulated shifted
+    if (pre_a) { pa = pre_a; nsa = nblk_a; x0a = nullptr; }
+    else nsa = launch_fwd_stats(xas, partial, M, C, (int64_t)C, stream);
+    if (pre_b) { pb = pre_b; nsb = nblk_b; x0b = nullptr; }
+    else nsb = launch_fwd_stats(xbs, partial + dtf_bn_partial_floats(M, C), M, C, (int64_t)C, stream);
     const float inv_count = 1.0f / (float)M;
     const float unbias = M > 1 ? (float)M / (float)(M - 1) : 1.f;
     const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
@@ -1421,10 +1427,10 @@ int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const
     do {                                                                                                                      \
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pa, nsa, C, inv_count, unbias,   \
                            gamma_a, beta_a, rm_a, rv_a, momentum_a, eps_a, stats_a, stats_a + C, stats_a + 2 * C,             \
-                           stats_a + 3 * C, xas);                                                                             \
+                           stats_a + 3 * C, x0a);                                                                             \
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<PDT>), dim3(fgrid), dim3(256), 0, stream, pb, nsb, C, inv_count, unbias,   \
                            gamma_b, beta_b, rm_b, rv_b, momentum_b, eps_b, stats_b, stats_b + C, stats_b + 2 * C,             \
-                           stats_b + 3 * C, xbs);                                                                             \
+                           stats_b + 3 * C, x0b);                                                                             \
     } while (0)
     if (param_dtype == DTF_BF16) FIN(DTF_BF16); else FIN(DTF_F32);
 #undef FIN
@@ -1439,6 +1445,24 @@ int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const
                        stats_b + 2 * C, stats_b + 3 * C, (unsigned short*)y, (unsigned char*)mask, M, C, rpb);
     DTF_CHECK_LAUNCH();
     return 0;
+}
+
+int dtf_bn2_fwd_train(const void* xa, const void* xb, void* y, void* mask, const void* gamma_a, const void* beta_a,
+                      const void* gamma_b, const void* beta_b, int param_dtype, float* rm_a, float* rv_a, float* rm_b,
+                      float* rv_b, float momentum_a, float eps_a, float momentum_b, float eps_b, float* stats_a,
+                      float* stats_b, float* partial, int64_t M, int C, hipStream_t stream) {
+    return bn2_fwd_train_impl(xa, xb, y, mask, gamma_a, beta_a, gamma_b, beta_b, param_dtype, rm_a, rv_a, rm_b, rv_b, momentum_a,
+                              eps_a, momentum_b, eps_b, stats_a, stats_b, partial, M, C, nullptr, 0, nullptr, 0, stream);
+}
+
+// the same with statistics partials of xa and / or xb from their producers (fp32 [nblk][2][C] plain sums; null: own pass)
+int dtf_bn2_fwd_train_pre(const void* xa, const void* xb, void* y, void* mask, const void* gamma_a, const void* beta_a,
+                          const void* gamma_b, const void* beta_b, int param_dtype, float* rm_a, float* rv_a, float* rm_b,
+                          float* rv_b, float momentum_a, float eps_a, float momentum_b, float eps_b, float* stats_a,
+                          float* stats_b, float* partial, int64_t M, int C, const float* pre_a, int nblk_a, const float* pre_b,
+                          int nblk_b, hipStream_t stream) {
+    return bn2_fwd_train_impl(xa, xb, y, mask, gamma_a, beta_a, gamma_b, beta_b, param_dtype, rm_a, rv_a, rm_b, rv_b, momentum_a,
+                              eps_a, momentum_b, eps_b, stats_a, stats_b, partial, M, C, pre_a, nblk_a, pre_b, nblk_b, stream);
 }
 
 // backward of dtf_bn2_fwd_train.  dgb_a / dgb_b: param dtype [2][C] = dgamma, dbeta; coef: fp32 [2][3][C] workspace

@@ -277,3 +277,40 @@ def test_conv1x1_k17_matches_reference(dev, cfg):
     r2.backward(g.to(torch.bfloat16).float())
     assert float((x.grad.float() - x2.grad).norm() / x2.grad.norm()) < 3e-2
     assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 3e-2
+
+
+def test_bn2_node_with_k17_partials(dev):
+    """relu(BN_a(conv_a(x)) + BN_b(conv_b(x))) with both 64 -> 256 products on K17 and their statistics partials handed to
+    the dual-BatchNorm node (dtf_bn2_fwd_train_pre) == the same node computing its own statistics; running statistics too."""
+    from distributed_tensorflow_amd.ops import batchnorm as bnmod, conv
+
+    torch.manual_seed(1)
+    N, H, W = 32, 56, 56
+    x = torch.randn(N, 64, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ca = conv.Conv1x1(64, 256).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    cb = conv.Conv1x1(64, 256).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    out = []
+    for pre in (True, False, "a"):
+        bna = bnmod.FusedBatchNormAct(256, relu=True).to(dev).to(torch.bfloat16).train()
+        bnb = bnmod.FusedBatchNormAct(256, relu=False).to(dev).to(torch.bfloat16).train()
+        with torch.no_grad():
+            bna.weight.copy_(torch.linspace(0.5, 1.5, 256)); bnb.bias.copy_(torch.linspace(-0.3, 0.3, 256))
+        xi = x.clone().requires_grad_()
+        ca.weight.grad = cb.weight.grad = None
+        ya, pa = ca.forward_stats(xi)
+        yb, pb = cb.forward_stats(xi)
+        assert pa is not None and pb is not None
+        if pre is True:
+            r = bnmod.fused_bn2_add_relu(ya, bna, yb, bnb, pa, pb)
+        elif pre == "a":
+            r = bnmod.fused_bn2_add_relu(ya, bna, yb, bnb, pa, None)
+        else:
+            r = bnmod.fused_bn2_add_relu(ya, bna, yb, bnb)
+        assert "BN2" in type(r.grad_fn).__name__
+        r.backward(torch.ones_like(r) * 0.01)
+        out.append((r.detach().float(), xi.grad.float(), bna.running_var.float().clone(), bnb.running_mean.float().clone()))
+    for o in (out[0], out[2]):
+        torch.testing.assert_close(o[0], out[1][0], rtol=2e-2, atol=2e-2)
+        assert float((o[1] - out[1][1]).norm() / out[1][1].norm()) < 1e-2
+        torch.testing.assert_close(o[2], out[1][2], rtol=1e-2, atol=1e-3)
+        torch.testing.assert_close(o[3], out[1][3], rtol=1e-2, atol=1e-3)
