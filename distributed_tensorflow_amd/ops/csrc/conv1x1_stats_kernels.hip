@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stats_kernel(P1Args a) {
             const int pos = PPP * j + lane / CPS;
             const int c = (lane % CPS) ^ (pos & (CPS - 1));
             const int64_t px = (int64_t)tile * P1_T + pos;
-            const unsigned short* src = px < a.M ? a.x + px * a.Cin + c * 8 : a.zero;
+            const unsigned short* src = px < a.M ? a.x + DTF_IDX(px * a.Cin + c * 8, a.M * a.Cin - 7, "K17 input tile edge") : a.zero;
             __builtin_amdgcn_global_load_lds((p1_glb_void*)src, (p1_lds_void*)(base + j * 1024), 16, 0, 0);
         }
     };
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stats_kernel(P1Args a) {
                         o[2 * j] = pack_bf16x2(acc[u][j][0], acc[u][j][1]);
                         o[2 * j + 1] = pack_bf16x2(acc[u][j][2], acc[u][j][3]);
                     }
-                    unsigned short* yp = a.y + px * a.Cout + ch0;
+                    unsigned short* yp = a.y + DTF_IDX(px * a.Cout + ch0, a.M * a.Cout - 4 * NJ + 1, "K17 output tile edge");
 #pragma unroll
                     for (int v = 0; v < NJ / 2; ++v)
                         *reinterpret_cast<u32x4*>(yp + 8 * v) = (u32x4){o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]};

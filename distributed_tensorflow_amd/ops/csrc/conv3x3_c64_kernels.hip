@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     u32x4 o0;
                     o0[0] = pack_bf16x2(acc[u][0][0], acc[u][0][1]); o0[1] = pack_bf16x2(acc[u][0][2], acc[u][0][3]);
                     o0[2] = pack_bf16x2(acc[u][1][0], acc[u][1][1]); o0[3] = pack_bf16x2(acc[u][1][2], acc[u][1][3]);
-                    unsigned short* yp = a.y + (((int64_t)n * a.H + oh) * W + ow[u]) * C3_C + chalf * 32 + qd * 8;
+                    unsigned short* yp = a.y + DTF_IDX((((int64_t)n * a.H + oh) * W + ow[u]) * C3_C + chalf * 32 + qd * 8,
+                                                       (int64_t)a.NB * a.H * W * C3_C - 7, "K16 output strip edge");
                     *reinterpret_cast<u32x4*>(yp) = o0;
                     if (a.partial) {          // statistics of what the consumer reads: the rounded values
 #pragma unroll

@@ -200,7 +200,8 @@ __device__ __forceinline__ void stem_fwd_body(const StemFwdArgs& a) {
                 u32x4 o0;
                 o0[0] = pack_bf16x2(acc[0][0], acc[0][1]); o0[1] = pack_bf16x2(acc[0][2], acc[0][3]);
                 o0[2] = pack_bf16x2(acc[1][0], acc[1][1]); o0[3] = pack_bf16x2(acc[1][2], acc[1][3]);
-                unsigned short* yp = a.y + (((int64_t)n * a.OH + oh) * a.OW + ow) * ST_C + chalf * 32 + qd * 8;
+                unsigned short* yp = a.y + DTF_IDX((((int64_t)n * a.OH + oh) * a.OW + ow) * ST_C + chalf * 32 + qd * 8,
+                                                   (int64_t)a.NB * a.OH * a.OW * ST_C - 7, "K15 output strip edge");
                 *reinterpret_cast<u32x4*>(yp) = o0;
                 {
                 // statistics of what the consumer reads: the rounded values
