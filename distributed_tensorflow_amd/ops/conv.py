@@ -117,11 +117,78 @@ def _rows(x):
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
 
 
+# K18 (csrc/conv1x1_n64_kernels.hip): register-streaming product onto 64 channels (K = 64 / 256): the stage-1 squeeze
+# layers' forward and the expand layers' data gradient (library: 125 us at K = 256, 64 / 76 us at K = 64)
+_N64 = os.environ.get("DTF_CONV1X1_N64", "1") != "0"
+_N64_MIN_ROWS = int(os.environ.get("DTF_CONV1X1_N64_MIN_ROWS", "65536"))
+_n64_declared = False
+
+
+def mm_n64_ok(x2, k, n):
+    """``x2`` [M, k] bf16 rows, product onto ``n`` channels: can K18 take it?"""
+    if not (_N64 and _ENABLED and n == 64 and k in (64, 256) and x2.is_cuda and x2.dtype == torch.bfloat16 and x2.dim() == 2
+            and x2.shape[1] == k and x2.shape[0] % 16 == 0 and x2.shape[0] >= _N64_MIN_ROWS and x2.is_contiguous()
+            and x2.data_ptr() % 16 == 0):
+        return False
+    from . import hip
+
+    return hasattr(hip.lib(), "dtf_conv1x1_n64")
+
+
+def mm_n64(x2, w2):
+    """``x2 [M, K] . w2 [64, K]^T -> [M, 64]`` (bf16) on K18."""
+    global _n64_declared
+    import ctypes
+
+    from . import hip
+
+    lib = hip.lib()
+    if not _n64_declared:
+        P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        hip.declare("dtf_conv1x1_n64", [P, P, P, L, I, P])
+        _n64_declared = True
+    if not w2.is_contiguous():
+        w2 = w2.contiguous()
+    M, K = x2.shape
+    assert tuple(w2.shape) == (64, K) and w2.dtype == torch.bfloat16
+    y2 = torch.empty(M, 64, dtype=x2.dtype, device=x2.device)
+    rc = lib.dtf_conv1x1_n64(hip.ptr(x2), hip.ptr(w2), hip.ptr(y2), M, K, hip.stream())
+    hip.check(rc, "dtf_conv1x1_n64")
+    return y2
+
+
+def _fwd_n64(x, weight):
+    """-> ``conv1x1(x, weight)`` on K18 or None."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cout != 64 or weight.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+        return None
+    x2 = _rows(x)
+    if not mm_n64_ok(x2, cin, cout):
+        return None
+    N, _, H, W = x.shape
+    return mm_n64(x2, weight.reshape(cout, cin)).view(N, H, W, cout).permute(0, 3, 1, 2)
+
+
+def _dgrad_n64(dy, weight):
+    """-> data gradient ``dy . w`` of a 1x1 convolution with 64 input channels on K18 or None (``dy`` NHWC-dense)."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    if cin != 64 or weight.dtype != torch.bfloat16:
+        return None
+    dy2 = _rows(dy)
+    if not mm_n64_ok(dy2, cout, cin):
+        return None
+    N, _, H, W = dy.shape
+    return mm_n64(dy2, weight.reshape(cout, cin).t().contiguous()).view(N, H, W, cin).permute(0, 3, 1, 2)
+
+
 class _Conv1x1Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, mm_fwd=False):
         ctx.save_for_backward(x, weight)
         cout, cin = weight.shape[0], weight.shape[1]
+        y = _fwd_n64(x, weight)
+        if y is not None:
+            return y
         if mm_fwd or _mm_fwd(x, weight):
             y2 = torch.matmul(_rows(x), weight.reshape(cout, cin).t())
             N, _, H, W = x.shape
@@ -136,6 +203,9 @@ class _Conv1x1Fn(torch.autograd.Function):
             dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
         need_dx, need_dw = ctx.needs_input_grad[:2]
+        if need_dx:
+            dx = _dgrad_n64(dy, weight)
+            need_dx = dx is None
         if need_dx and _mm_dgrad(dy, weight):
             N, _, H, W = x.shape
             dx = torch.matmul(_rows(dy), weight.reshape(cout, cin)).view(N, H, W, cin).permute(0, 3, 1, 2)
@@ -285,7 +355,10 @@ class _Conv1x1ForkFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.own = bool(own_skip_grad)
         cout, cin = weight.shape[0], weight.shape[1]
-        if _mm_fwd(x, weight):
+        y = _fwd_n64(x, weight)
+        if y is not None:
+            pass
+        elif _mm_fwd(x, weight):
             N, _, H, W = x.shape
             y = torch.matmul(_rows(x), weight.reshape(cout, cin).t()).view(N, H, W, cout).permute(0, 3, 1, 2)
         else:

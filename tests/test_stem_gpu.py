@@ -314,3 +314,40 @@ def test_bn2_node_with_k17_partials(dev):
         assert float((o[1] - out[1][1]).norm() / out[1][1].norm()) < 1e-2
         torch.testing.assert_close(o[2], out[1][2], rtol=1e-2, atol=1e-3)
         torch.testing.assert_close(o[3], out[1][3], rtol=1e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("k", [64, 256])
+@pytest.mark.parametrize("rows", [65536 + 16, 16 * 12345])
+def test_conv1x1_n64_k18_matches_reference(dev, k, rows):
+    """K18 (register-streaming product onto 64 channels) vs fp32 on NaN-poisoned output memory; then a Conv1x1 k -> 64
+    forward and a 64 -> k data gradient through the module path vs the fp32 composition."""
+    from distributed_tensorflow_amd.ops import conv
+
+    torch.manual_seed(k + rows)
+    x2 = torch.randn(rows, k, device=dev).to(torch.bfloat16)
+    w2 = (torch.randn(64, k, device=dev) / k ** 0.5).to(torch.bfloat16)
+    assert conv.mm_n64_ok(x2, k, 64)
+    y = conv.mm_n64(x2, w2)
+    ref = x2.float() @ w2.float().t()
+    assert torch.isfinite(y).all()
+    assert float((y.float() - ref).norm() / ref.norm()) < 5e-3
+    torch.testing.assert_close(y.float(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_conv1x1_n64_module_paths(dev):
+    from distributed_tensorflow_amd.ops import conv
+
+    torch.manual_seed(3)
+    N, H, W = 32, 56, 56
+    for cin, cout in ((256, 64), (64, 256), (64, 64)):
+        x = torch.randn(N, cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+        m = conv.Conv1x1(cin, cout).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+        y = m(x)
+        x2, w2 = x.detach().float().requires_grad_(), m.weight.detach().float().requires_grad_()
+        c2 = F.conv2d(x2, w2)
+        assert float((y.detach().float() - c2.detach()).norm() / c2.detach().norm()) < 5e-3
+        g = torch.randn_like(c2).to(torch.bfloat16)
+        y.backward(g)
+        c2.backward(g.float())
+        assert float((x.grad.float() - x2.grad).norm() / x2.grad.norm()) < 5e-3
+        assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 2e-2
