@@ -70,7 +70,7 @@ class _SplitDeepWide(torch.autograd.Function):
 class WideDeep(nn.Module):
     def __init__(self, comm=None, device=None, num_features=26, rows_per_table=100000, embedding_dim=64,
                  dense_features=13, hidden=(1024, 512, 256), emb_optimizer="adagrad", emb_lr=0.05, atomic=False,
-                 partition="mod", route="capacity", capacity_factor=1.25):
+                 partition="mod", route="auto", capacity_factor=1.25):
         super().__init__()
         comm = comm or Comm.single()
         if isinstance(rows_per_table, (list, tuple)):

@@ -139,6 +139,39 @@ class Comm:
     def _local(self, r):
         return r if self.group is None else dist.get_group_rank(self.group, r)
 
-    def close(self):
-        if self.live and self.group is None and dist.is_initialized():
-            dist.destroy_process_group()
+    def close(self, timeout_s=None, on_timeout_exit=None):
+        """Tear the process group down (``destroy_process_group``).  A task that reaches interpreter exit with a
+        live gloo / RCCL group dies in ``std::terminate`` ("terminate called without an active exception": the
+        backend's worker threads are still joinable when the static destructors run) -- a rank that had FINISHED
+        its job then reports a failure exit code, and the reference's lifecycle keys everything off
+        ``status.succeeded == 1`` (``/root/reference/eventHandlers/CleanJobHandler.py:48-59``).
+
+        ``timeout_s`` + ``on_timeout_exit``: on an error path the peers may be gone and the destroy may block
+        (RCCL waits for outstanding work); after ``timeout_s`` the process ends with ``on_timeout_exit``."""
+        if not (self.live and dist.is_initialized()):
+            self.live = False
+            return
+        timer = None
+        if timeout_s and on_timeout_exit is not None:
+            import sys
+            import threading
+
+            def _bail():
+                try:
+                    sys.stdout.flush()
+                    sys.stderr.flush()
+                finally:
+                    os._exit(int(on_timeout_exit))
+
+            timer = threading.Timer(float(timeout_s), _bail)
+            timer.daemon = True
+            timer.start()
+        try:
+            if self.group is None:
+                dist.destroy_process_group()
+            else:
+                dist.destroy_process_group(self.group)
+        finally:
+            if timer is not None:
+                timer.cancel()
+            self.live = False

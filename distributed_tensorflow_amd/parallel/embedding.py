@@ -21,15 +21,32 @@ The sparse optimizer step is fused into backward on the owning rank (exactly
 where TF1 runs SparseApplyAdagrad: on the PS); the table is not a dense
 ``nn.Parameter`` and never enters the dense push/pull buckets.
 
-Routing never touches the host (``route="capacity"``, the default): a stable
-bucket-by-owner HIP kernel (``ops/csrc/route_kernels.hip``) places request i at
-slot ``owner * cap + rank_i`` of a fixed-capacity send list, so the three
-all-to-alls have constant, equal splits -- no sort, no ``bincount``, no
-``.tolist()``; the rows come back through the same slots and are un-permuted by a
-K3 gather.  ``cap = capacity_factor * N / W`` (MoE-style); requests beyond it are
-dropped and counted on the device, and :meth:`check_overflow` (polled every few
-hundred steps, the only host read) grows the capacity and reports.  ``route="exact"``
-keeps the variable-split exchange (one host sync per step) for debugging.
+Routing (``route=``):
+
+``"exact"``     variable-split exchange: sort by owner, exchange the counts, one host
+                read per step.  Never drops a request -- the semantics of the PS-hosted
+                partitioned variables this replaces (a TF1 PS answers every ``Gather``).
+``"capacity"``  never touches the host: a stable bucket-by-owner HIP kernel
+                (``ops/csrc/route_kernels.hip``) places request i at slot
+                ``owner * cap + rank_i`` of a fixed-capacity send list, so the three
+                all-to-alls have constant, equal splits -- no sort, no ``bincount``, no
+                ``.tolist()``; the rows come back through the same slots and are
+                un-permuted by a K3 gather.  ``cap = capacity_factor * N / W``
+                (MoE-style); requests beyond it are DROPPED (zero rows forward, no
+                sparse update) and counted on the device.  Lossy: opt-in only.
+``"auto"``      the default.  The first ``calibrate`` lookups run the exact route and
+                measure the largest (source, owner) load, all-reduced (MAX) so every
+                rank agrees; after that the capacity route runs with ``cap`` sized from
+                that measurement (x ``capacity_margin``), i.e. from the data's real skew
+                (one low-cardinality feature sends its whole batch to <= 3 owners)
+                rather than from a guessed factor.  The overflow counter is polled after
+                capacity lookups 1, 2, 4, 8, ... and then every ``overflow_check_every``;
+                an overflow grows the capacity and sends the module back to the exact
+                route for another calibration.
+
+:meth:`check_overflow` is a COLLECTIVE: the per-rank counters (counted on the sending
+rank) are all-reduced (MAX) before anybody decides to grow, so ``capacity_factor`` -- and
+with it the split sizes of the equal-split all-to-alls -- stays identical on every rank.
 """
 from __future__ import annotations
 
@@ -56,8 +73,8 @@ class _Lookup(torch.autograd.Function):
 class ShardedEmbedding(nn.Module):
     def __init__(self, table_rows, dim, comm: Comm = None, device=None, table_dtype=torch.float32,
                  out_dtype=None, optimizer="adagrad", lr=0.01, eps=1e-10, init_std=0.01, atomic=False,
-                 names=None, seed=1234, initial_accumulator=0.1, partition="mod", route="capacity",
-                 capacity_factor=1.25, overflow_check_every=200):
+                 names=None, seed=1234, initial_accumulator=0.1, partition="mod", route="auto",
+                 capacity_factor=1.25, overflow_check_every=200, calibrate=2, capacity_margin=1.5):
         super().__init__()
         self.comm = comm or Comm.single()
         self.dim = int(dim)
@@ -68,10 +85,14 @@ class ShardedEmbedding(nn.Module):
             offs.append(tot)
             tot += r
         self.total_rows = tot
-        assert partition in ("mod", "div") and route in ("capacity", "exact")
+        assert partition in ("mod", "div") and route in ("auto", "capacity", "exact")
         self.partition, self.route = partition, route
         self.capacity_factor = float(capacity_factor)
         self.overflow_check_every = int(overflow_check_every)
+        self.calibrate, self.capacity_margin = max(1, int(calibrate)), float(capacity_margin)
+        self._calibrating = self.calibrate if route == "auto" else 0     # exact lookups left before the switch
+        self._max_pair_load = 0.0       # largest (source, owner) load seen while calibrating, relative to n / W
+        self._routed_lookups = 0
         W, r = self.comm.world_size, self.comm.rank
         self.rows_per = (tot + W - 1) // W                       # div: rows per part
         self.local_rows = self.part_rows(r, W)
@@ -155,19 +176,58 @@ class ShardedEmbedding(nn.Module):
         return max(64, min(n, (c + 63) // 64 * 64))
 
     def check_overflow(self, grow=True):
-        """The only host read of the routed path: requests dropped since the last check.  On overflow the
-        capacity factor grows (x1.5) so that later steps are exact again, and a warning names the loss."""
-        dropped = int(self.overflow.item())
+        """The only host read of the routed path, and a COLLECTIVE (every rank must call it at the same lookup
+        count -- ``_forward_impl`` does): the largest number of requests any rank dropped since the last check.
+        The counter lives on the SENDING rank (``route_kernels.hip``), so without the all-reduce only the ranks
+        that overflowed would grow their factor and the next equal-split all-to-all would be issued with
+        different sizes on different ranks (an RCCL hang, or rows in the wrong slots).  On overflow every rank
+        grows the factor by the same x1.5; ``route="auto"`` additionally re-calibrates on the exact route."""
+        if self.comm.live and self.comm.world_size > 1:
+            worst = self.overflow.clone()
+            self.comm.all_reduce(worst, op=torch.distributed.ReduceOp.MAX)
+            dropped, mine = int(worst.item()), int(self.overflow.item())
+        else:
+            dropped = mine = int(self.overflow.item())
         if dropped:
             self.overflow.zero_()
-            self.dropped_total += dropped
-            msg = "[embedding] %d lookups exceeded the all-to-all capacity (factor %.2f) and were dropped" % (
-                dropped, self.capacity_factor)
+            self.dropped_total += mine
+            msg = "[embedding] up to %d lookups per rank (%d here) exceeded the all-to-all capacity (factor %.2f) " \
+                  "and were dropped" % (dropped, mine, self.capacity_factor)
             if grow:
                 self.capacity_factor *= 1.5
-                msg += "; capacity factor -> %.2f" % self.capacity_factor
+                msg += "; capacity factor -> %.2f on every rank" % self.capacity_factor
+                if self.route == "auto":
+                    self._calibrating = self.calibrate
+                    msg += "; re-calibrating on the exact route"
             print(msg, flush=True)
         return dropped
+
+    def _poll_due(self):
+        """Capacity lookups 1, 2, 4, 8, ... (a bad factor shows on the first step, not after 200), then every
+        ``overflow_check_every``.  A function of the lookup count alone: identical on every rank."""
+        k, every = self._routed_lookups, self.overflow_check_every
+        if not every:
+            return False
+        if k < every:
+            return k & (k - 1) == 0
+        return k % every == 0
+
+    def _calibrated(self, sc, n):
+        """One exact lookup of the calibration phase is done: fold its largest (source, owner) load into the
+        running maximum (all-reduced: one agreed number); after the last one, size the capacity from it."""
+        W = self.comm.world_size
+        load = torch.tensor([max(sc) / max(n / W, 1.0)], dtype=torch.float32, device=self.table.device)
+        if self.comm.live and W > 1:
+            self.comm.all_reduce(load, op=torch.distributed.ReduceOp.MAX)
+        self._max_pair_load = max(self._max_pair_load, float(load.item()))
+        self._calibrating -= 1
+        if self._calibrating == 0:
+            self.capacity_factor = max(self.capacity_factor, self._max_pair_load * self.capacity_margin)
+            self._max_pair_load = 0.0
+            self._routed_lookups = 0
+            if self.comm.rank == 0:
+                print("[embedding] capacity factor %.2f from the measured owner load (x%.2f margin)" % (
+                    self.capacity_factor, self.capacity_margin), flush=True)
 
     # ------------------------------------------------------------ internals
     def _route_exact(self, flat_ids):
@@ -189,8 +249,10 @@ class ShardedEmbedding(nn.Module):
             rows = emb_ops.embedding_gather(self.table, flat_ids, self.out_dtype)
             return rows, ("local", flat_ids)
         dev = flat_ids.device
-        if self.route == "exact":
+        if self.route == "exact" or self._calibrating:
             order, send_ids, sc, rc = self._route_exact(flat_ids)
+            if self._calibrating:
+                self._calibrated(sc, flat_ids.numel())
             local = torch.empty(sum(rc), dtype=torch.int64, device=dev)
             self.comm.all_to_all(local, send_ids, rc, sc)
             rows = emb_ops.embedding_gather(self.table, local, self.out_dtype)
@@ -211,7 +273,8 @@ class ShardedEmbedding(nn.Module):
         self.comm.all_to_all(back, rows)
         out = emb_ops.embedding_gather(back, slot, self.out_dtype)                     # un-permute (dropped -> zeros)
         self._lookups += 1
-        if self.overflow_check_every and self._lookups % self.overflow_check_every == 0:
+        self._routed_lookups += 1
+        if self._poll_due():
             self.check_overflow()
         return out, ("routed", recv_ids, inv)
 

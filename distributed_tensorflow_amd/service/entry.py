@@ -200,5 +200,31 @@ def main(argv=None):
     return rc
 
 
+def leave(rc):
+    """End a task process with ``rc`` as its exit status.  The task is a leaf: its exit code is the Job's
+    ``status.succeeded`` / ``status.failed`` (the only thing the reference's lifecycle reads,
+    ``/root/reference/eventHandlers/CleanJobHandler.py:48``), so it must reflect the training result and not the
+    order in which third-party libraries (HIP runtime, RCCL, gloo) run their static destructors at interpreter
+    exit.  The process group is already destroyed (``trainer.run_task``); after flushing, skip the destructors.
+    ``DTF_HARD_EXIT=0`` restores a plain ``sys.exit``."""
+    rc = int(rc or 0)
+    if os.environ.get("DTF_HARD_EXIT", "1") == "0":
+        sys.exit(rc)
+    try:
+        sys.stdout.flush()
+        sys.stderr.flush()
+    finally:
+        os._exit(rc)
+
+
 if __name__ == "__main__":
-    sys.exit(main() or 0)
+    try:
+        _rc = main()
+    except SystemExit as e:         # ps_join_forever's SIGTERM handler, argparse
+        _rc = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+    except BaseException:           # noqa: BLE001 -- the traceback belongs in the task log, the code in the Job status
+        import traceback
+
+        traceback.print_exc()
+        _rc = 1
+    leave(_rc)

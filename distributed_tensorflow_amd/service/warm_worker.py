@@ -68,4 +68,15 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    from .entry import leave
+
+    try:
+        _rc = main()
+    except SystemExit as e:
+        _rc = e.code if isinstance(e.code, int) else (0 if e.code is None else 1)
+    except BaseException:           # noqa: BLE001
+        import traceback
+
+        traceback.print_exc()
+        _rc = 1
+    leave(_rc)

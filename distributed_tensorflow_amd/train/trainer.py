@@ -170,6 +170,26 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
 
 def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_dir, export_dir, metrics,
              t_start=None):
+    """One task of a job, from rendezvous to teardown.  Whatever way the body ends -- worker done, ps task done
+    serving, exception -- the process group is destroyed before the caller gets control back: a task that leaves
+    the interpreter with a live gloo / RCCL group aborts in ``std::terminate`` and turns a finished job into a
+    failed one (``Comm.close``)."""
+    comms = []
+    ok = False
+    try:
+        rc = _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_dir, export_dir, metrics,
+                       t_start, comms)
+        ok = rc == 0
+        return rc
+    finally:
+        for c in comms:
+            # success: every rank has passed the final barrier, the destroy is immediate.  Failure: peers may be
+            # stuck in a collective this rank will never join -- bounded destroy, then a hard exit with the error
+            c.close(timeout_s=None if ok else 15.0, on_timeout_exit=None if ok else 1)
+
+
+def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_dir, export_dir, metrics,
+              t_start, comms):
     t_start = t_start or time.time()
     trace = os.environ.get("DTF_TRACE_START", "0") == "1"
 
@@ -192,6 +212,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     # DTF_FORCE_COMM=1: keep a live process group even with one rank (the collectives then really run: 1-GPU rehearsal)
     comm = Comm.from_env(device, backend="gloo" if one_sided else None,
                          force=bool(int(os.environ.get("DTF_FORCE_COMM", "0"))) and not one_sided)
+    comms.append(comm)
     chief = job_name == "worker" and task_index == 0
     mark("communicator ready")
     if chief:
@@ -309,5 +330,8 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     if chief:
         metrics(t_done=time.time(), step=ps.global_step, items_per_sec=rate,
                 final_loss=last if last is not None else "nan")
-    comm.barrier() if placement != "dedicated" else None
+    # last collective of the job: nobody tears the group down while a peer still needs it (the dedicated
+    # placement passed its barrier above, after the ps tasks wrote their shards)
+    if placement != "dedicated":
+        comm.barrier()
     return 0

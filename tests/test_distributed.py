@@ -179,11 +179,14 @@ def test_checkpoint_resharding_2_to_4_ranks(tmp_path):
         torch.testing.assert_close(resumed["params"][n], p, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("case,world", [("widedeep", 2), ("widedeep", 4), ("widedeep_div", 2), ("widedeep_exact", 2)])
+@pytest.mark.parametrize("case,world", [("widedeep", 2), ("widedeep", 4), ("widedeep_div", 2), ("widedeep_exact", 2),
+                                        ("widedeep_capacity", 2)])
 def test_sharded_embedding_equals_single_rank(tmp_path, case, world):
     """Config #3 plumbing: ids all-to-all -> owner gather -> rows all-to-all; backward:
-    row grads all-to-all -> sort/segment sparse Adagrad on the owner.  Default route = fixed-capacity,
-    device-side bucket-by-owner (no host sync); ``_exact`` = variable splits; ``_div`` = range partition."""
+    row grads all-to-all -> sort/segment sparse Adagrad on the owner.  Default route = ``auto`` (two calibration
+    lookups on the exact route, then fixed-capacity device-side bucket-by-owner without host sync -- the five steps
+    cross the switch); ``_exact`` = variable splits; ``_capacity`` = fixed capacity from the first lookup;
+    ``_div`` = range partition."""
     one = run_ranks(1, "widedeep", tmp_path)
     many = run_ranks(world, case, tmp_path)
     assert many["dropped"] == 0
@@ -198,6 +201,24 @@ def test_embedding_capacity_overflow_is_counted(tmp_path):
     """A capacity factor below 1 must drop lookups, count them on the device and report them (never silently)."""
     res = run_ranks(2, "widedeep_tight", tmp_path)
     assert res["dropped"] > 0
+
+
+def test_embedding_overflow_poll_is_collective_and_grows_every_rank(tmp_path):
+    """only rank 0 overflows; every rank must end up with the same capacity factor after each
+    poll (asserted inside the workers after every lookup), the factor must have grown, and from some lookup on the
+    routed lookups are exact on every rank."""
+    res = run_ranks(2, "embgrow_capacity", tmp_path)
+    assert res["dropped"] > 0
+    assert res["factors"][-1] > res["factors"][0] and res["factors"][0] >= 0.6
+    assert res["exact_after"] is not None and res["exact_after"] <= 8, res
+
+
+def test_embedding_default_route_is_lossless_on_skewed_ids(tmp_path):
+    """the default route sizes its capacity from the measured owner load instead of dropping
+    lookups silently: same skewed ids, same bad initial factor -- nothing is dropped, every lookup is exact."""
+    res = run_ranks(2, "embgrow_auto", tmp_path)
+    assert res["dropped"] == 0 and res["exact_after"] == 0, res
+    assert res["factors"][-1] >= 2.0        # rank 0 sends everything to one of two owners: load 2 x the mean
 
 
 @pytest.mark.parametrize("resume_case,world", [("widedeep_resume", 4), ("widedeep_resume_div", 2), ("widedeep_resume", 1)])

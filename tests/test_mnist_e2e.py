@@ -130,3 +130,28 @@ def test_dedicated_checkpoint_resumes_in_the_colocated_placement(aio):
     second = CheckpointReader(export)
     assert second.step == 30 and second.world == 2
     assert (second.read("hid_w") - w_before).abs().max() > 0
+
+
+@pytest.mark.parametrize("placement,ps", [("colocated", 1), ("dedicated", 2)])
+def test_eight_workers_every_task_exits_zero(aio, placement, ps):
+    """Round-2 record: a W=8 job whose ranks had all printed "done" was recorded FAILED because a rank left the
+    interpreter with a live process group (``terminate called without an active exception``).  Every exit path of a
+    task now destroys its group first; this is the regression test: W=8 over gloo through the REST path, the job
+    ends "succeeded", every worker Job reports exit code 0 (the ``status.succeeded == 1`` the reference's lifecycle
+    keys on, /root/reference/eventHandlers/CleanJobHandler.py:48-59) and no task log shows an abort."""
+    a, port, tmp = aio
+    names = _post(port, {"file": "builtin://mnist_mlp?steps=12&batch=16&placement=%s&optimizer=momentum&lr=0.05"
+                                 "&log_every=4" % placement,
+                         "detail": {"ps": ps, "worker": 8}})
+    uid = parse_task_name(names[0])[0]
+    rec = _wait_final(a, uid, timeout=300)
+    logs = _logs(a)
+    assert rec["status"] == "succeeded", logs
+    workers = [n for n in names if "-worker-" in n]
+    assert len(workers) == 8
+    ns = ApiConfig().get("namespace", "tensorflow")
+    for n in workers:
+        st = a.cluster.read_namespaced_job(n, ns).status
+        assert st.succeeded == 1 and st.exitCode == 0, (n, dict(st), logs)
+    assert "terminate called" not in logs and "Aborted" not in logs, logs
+    assert logs.count("done: 12 steps") == 8, logs
