@@ -52,8 +52,13 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("DTF_MIOPEN_FIND", "0")),
                     help="1: let MIOpen benchmark each conv during warm-up (cudnn.benchmark)")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("DTF_BENCH_GRAPH", "0")),
-                    help="1: capture the whole step in a hipGraph (single GPU only)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DTF_BENCH_GRAPH", "-1")),
+                    help="1: capture the whole step (forward, backward, hook-launched PS pipeline incl. its RCCL "
+                         "collectives) in one hipGraph and replay it, any N, with automatic fallback to eager when the "
+                         "capture fails on any rank; 0: eager; -1 (default): 1 on one GPU (validated bitwise equal to "
+                         "eager there), 0 on several")
+    ap.add_argument("--lr-warmup-steps", type=int, default=100,
+                    help="gradual warm-up (Goyal et al.): lr = peak * min(1, step / N); 0: constant peak lr")
     ap.add_argument("--profile-dir", default="")
     a = ap.parse_args()
 
@@ -136,12 +141,28 @@ def main():
     if "seq_len" in kw:
         bkw["seq_len"] = int(kw["seq_len"])
     batch = mod.synthetic_batch(a.batch, device=dev, seed=100 + comm.rank, **bkw)
+    if a.graph < 0:
+        a.graph = 1 if (on_gpu and comm.world_size == 1 and a.update_mode != "async") else 0
 
-    def step():
+    # lr schedule: the learning rate lives in device memory (ps.hyper), so a captured graph replays with new values
+    peak_lr, sched = ps.lr, {"t": 0}
+
+    def next_lr():
+        sched["t"] += 1
+        if a.lr_warmup_steps > 0:
+            ps.set_lr(peak_lr * min(1.0, sched["t"] / float(a.lr_warmup_steps)))
+
+    def raw_step():
         loss = mod.loss_fn(model, batch)
         loss.backward()
         ps.step()
         return loss
+
+    def step():
+        next_lr()
+        return raw_step()
+
+    first_loss = None
 
     graph = None
     if a.graph and on_gpu:
@@ -153,7 +174,9 @@ def main():
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(max(3, a.warmup)):
-                step()
+                lw = step()
+                if first_loss is None:
+                    first_loss = float(lw.detach().float().item())
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         comm.barrier()
@@ -165,7 +188,7 @@ def main():
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                static_loss = step()
+                static_loss = raw_step()       # without the lr update: its fill would be replayed as a constant
             graph = g
         except Exception as e:       # noqa: BLE001 -- any capture failure means "run eagerly", never a dead bench
             print("[bench] rank %d: hipGraph capture failed (%s: %s); running eagerly" % (
@@ -180,11 +203,14 @@ def main():
             eager_step = step
 
             def step():  # noqa: F811
+                next_lr()
                 graph.replay()
                 return static_loss
     t_w = time.perf_counter()
     for i in range(a.warmup):
         loss = step()
+        if first_loss is None:
+            first_loss = float(loss.detach().float().item())
         if comm.rank == 0 and (i < 3 or a.miopen_find):
             dev_sync()
             print("[bench] warmup step %d done at +%.1f s" % (i + 1, time.perf_counter() - t_w), file=sys.stderr,
@@ -235,6 +261,8 @@ def main():
                        "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),
                        "host_enqueue_ms_per_step": round(t_probe * 1e3, 3),
                        "host_loop_ms_per_step": round(t_host / a.steps * 1e3, 3),
+                       "lr_warmup_steps": a.lr_warmup_steps, "lr_now": round(ps.lr, 5),
+                       "first_loss": None if first_loss is None else round(first_loss, 4),
                        "final_loss": round(last_loss, 4)},
         }
         sys.stdout.flush()
