@@ -135,6 +135,8 @@ def main():
         ps = ShardedPS(list(model.named_parameters()), comm, opt, bucket_mb=a.bucket_mb,
                        update_mode=a.update_mode, push=a.push, num_shards=a.num_ps or None,
                        staleness=a.staleness, wire_dtype=wire)
+    if a.update_mode == "sync" and hasattr(ps, "attach"):
+        ps.attach(model)        # forward-order pull prefetch (eager steps at N > 1; a no-op on one rank)
     bkw = {"image_size": a.image_size} if a.image_size else {}
     if getattr(mod, "NEEDS_COMM", False):
         bkw["model"] = model
@@ -185,6 +187,8 @@ def main():
         # illegal while a global-mode capture is open.  Let it retire them, and capture in thread-local mode.
         time.sleep(0.5)
         ok = torch.ones(1, device=dev)
+        if hasattr(ps, "disable_prefetch"):
+            ps.disable_prefetch()
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):

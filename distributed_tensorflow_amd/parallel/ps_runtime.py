@@ -36,7 +36,13 @@ slice j from rank j.
 
 Gradient clipping (``max_grad_norm``): packs and pushes still run from the backward
 hooks; only sum-of-squares -> scalar all-reduce -> apply -> pull wait for the end of
-backward.
+backward, and they then run in FORWARD layer order (the bucket of the first layers first).
+
+Pull prefetch (``attach(model)``): every bucket's pull records an event; forward pre-hooks
+make a layer wait for the event of ITS bucket only, so the next forward starts as soon as
+the first layers' parameters have arrived and the remaining all-gathers (BERT: ~220 MB
+after the clip all-reduce) run under it -- SURVEY 5.8 "forward-layer order for pull
+prefetch".  Without ``attach`` the next forward waits for the whole comm stream.
 """
 from __future__ import annotations
 
@@ -209,6 +215,17 @@ class ShardedPS:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         self._inflight = [None] * self.staleness      # per ring slot: event of the pipeline in flight (or True)
         self._last_slot = None
+        # stale mode: the packs run from the hooks too (on the comm stream, behind the pipeline still in flight)
+        if bool(overlap) and update_mode == "stale":
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad_stale))
+        # -- pull prefetch (see attach) ---------------------------------------
+        nb = len(L.buckets)
+        self._pull_events = [torch.cuda.Event() for _ in range(nb)] if self.is_cuda else [None] * nb
+        self._pull_pending = [False] * nb     # pulled on the comm stream, not yet waited for by the compute stream
+        self._prefetch = False                # per-bucket waits are live (attach + one learning step done)
+        self.prefetch_waits = 0               # per-bucket event waits issued so far (tests / diagnostics)
+        self._attached = None
 
     # ------------------------------------------------------------------ hooks
     def _on_grad(self, p):
@@ -219,6 +236,83 @@ class ShardedPS:
                 self._launch_bucket(b)
             else:
                 self._launch_push(b)
+
+    def _on_grad_stale(self, p):
+        b = self._slot_bucket[id(p)]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launched[b] = True
+            slot = self.global_step % self.staleness
+            with self._on_comm_stream():
+                with trace_range("ps/pack/b%d" % b):
+                    self._pack(b, self._grad_ring[slot])
+
+    # ------------------------------------------------------- pull prefetch
+    def attach(self, model, prefetch=None):
+        """Forward-order pull prefetch: instead of joining the whole comm stream before the next forward, every
+        module that owns parameters waits (forward pre-hook) for the pull event of the buckets holding THEM.
+
+        Parameters that are read outside their owner's ``forward`` (BERT's root module reads
+        ``word_embeddings.weight`` functionally, twice) cannot be caught by the owner's hook.  They are found by
+        observation: the first step after ``attach`` still joins the whole stream and records which owner modules
+        were called; the buckets of every owner that was NOT called are waited for at the root's pre-hook, i.e.
+        before anything runs.  ``DTF_PULL_PREFETCH=0`` (or ``prefetch=False``) keeps the global join."""
+        if prefetch is None:
+            prefetch = os.environ.get("DTF_PULL_PREFETCH", "1") != "0"
+        if not prefetch or not self.is_cuda or self._unpack_needed or self.update_mode != "sync" or not self._dist:
+            return self         # nothing to overlap (no comm stream work to wait for / parameters need an unpack)
+        bucket_of = {id(p): self._slot_bucket[id(p)] for p in self.params}
+        owners = {}
+        for m in model.modules():
+            bs = sorted({bucket_of[id(p)] for p in m._parameters.values() if p is not None and id(p) in bucket_of})
+            if bs:
+                owners[m] = bs
+        st = self._attached = {"owners": owners, "called": set(), "root": model, "root_buckets": None,
+                               "learning": True, "handles": []}
+
+        def owner_pre(m, args):
+            if st["learning"]:
+                st["called"].add(m)
+            elif self._prefetch:
+                self._wait_buckets(owners[m])
+
+        def root_pre(m, args):
+            if self._prefetch and st["root_buckets"]:
+                self._wait_buckets(st["root_buckets"])
+
+        def root_post(m, args, out):
+            if st["learning"]:
+                never = [b for mod, bs in owners.items() if mod not in st["called"] for b in bs]
+                st["root_buckets"] = sorted(set(never))
+                st["learning"] = False
+            elif self._prefetch:
+                self._wait_buckets(range(len(self.layout.buckets)))     # nothing may stay un-waited past forward
+
+        st["handles"].append(model.register_forward_pre_hook(root_pre))
+        for m in owners:
+            if m is not model:
+                st["handles"].append(m.register_forward_pre_hook(owner_pre))
+            else:
+                # the root owns parameters itself: they belong to the root set
+                st["called"].discard(m)
+        st["handles"].append(model.register_forward_hook(root_post))
+        return self
+
+    def _wait_buckets(self, buckets):
+        cur = None
+        for b in buckets:
+            if self._pull_pending[b]:
+                if cur is None:
+                    cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(self._pull_events[b])
+                self._pull_pending[b] = False
+                self.prefetch_waits += 1
+
+    def _pulled(self, b):
+        """Called on the comm stream right after bucket ``b``'s pull was enqueued."""
+        if self._pull_events[b] is not None:
+            self._pull_events[b].record(torch.cuda.current_stream(self.device))
+            self._pull_pending[b] = True
 
     @contextlib.contextmanager
     def _on_comm_stream(self):
@@ -333,6 +427,7 @@ class ShardedPS:
                 self._apply(b, pushed)
             with trace_range("ps/pull/b%d" % b):
                 self._pull(b)
+                self._pulled(b)
 
     def _launch_push(self, b):
         """Clipped path, from the hooks: pack -> push only; apply waits for the global norm."""
@@ -357,12 +452,32 @@ class ShardedPS:
                     self._launch_bucket(b)
             with self._on_comm_stream():
                 self.hyper[2:3].add_(1.0)
-            self._join()
+            self._join_or_prefetch()
         self._finish_step()
 
     def _join(self):
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        self._pull_pending = [False] * len(self._pull_pending)
+
+    def _join_or_prefetch(self):
+        """End of a sync step: either the next forward waits per bucket (prefetch live), or for everything."""
+        st = self._attached
+        if st is not None and not st["learning"] and st["root_buckets"] is not None \
+                and not torch.cuda.is_current_stream_capturing():
+            self._prefetch = True
+            return
+        self._join()
+
+    def disable_prefetch(self):
+        """Before a hipGraph capture: a captured step must rejoin the comm stream before the capture ends (and a
+        replay runs no Python hooks), so the per-bucket waits are switched off and everything pending is joined."""
+        self._prefetch = False
+        if self._attached is not None:
+            for h in self._attached["handles"]:
+                h.remove()
+            self._attached = None
+        self._join()
 
     def _step_clipped(self):
         """Global-norm clipping needs every reduced shard before any apply: the packs and pushes already ran
@@ -386,12 +501,17 @@ class ShardedPS:
             if first:
                 self.gnorm_sq.zero_()       # this rank hosts nothing (P < W): contributes 0 to the norm
             self.comm.all_reduce(self.gnorm_sq)
-            for b in range(nb):
-                self._apply(b, self._pushed[b])
-                self._pull(b)
+            # forward layer order (the last bucket holds the first layers): with the prefetch hooks the next
+            # forward starts after the FIRST of these pulls and runs under the others
+            for b in reversed(range(nb)):
+                with trace_range("ps/apply/b%d" % b):
+                    self._apply(b, self._pushed[b])
+                with trace_range("ps/pull/b%d" % b):
+                    self._pull(b)
+                    self._pulled(b)
             self.hyper[2:3].add_(1.0)
         self._pushed = [None] * nb
-        self._join()
+        self._join_or_prefetch()
 
     def _wait_slot(self, slot):
         ev = self._inflight[slot]
@@ -408,10 +528,13 @@ class ShardedPS:
         # 1. the pipeline launched `staleness` steps ago must be done; adopt its parameters
         if self._wait_slot(slot):
             self.param_flat.copy_(staging)
-        # 2. stage this step's gradients, then run the pipeline behind the
-        #    next `staleness` forward/backward passes
-        for b in range(nb):
-            self._pack(b, ring)
+        # 2. stage this step's gradients (the hooks packed most buckets behind backward already), then run the
+        #    pipeline behind the next `staleness` forward/backward passes
+        with self._on_comm_stream():
+            for b in range(nb):
+                if not self._launched[b]:
+                    self._launched[b] = True
+                    self._pack(b, ring)
         with self._on_comm_stream():
             first = True
             pushed = []
@@ -451,6 +574,19 @@ class ShardedPS:
         self._launched = [False] * len(self.layout.buckets)
         self.global_step += 1
 
+    def reset_step_state(self, global_step=None):
+        """Forget a half-issued step (a hipGraph capture that failed midway ran no kernel but did move the host-side
+        bookkeeping): hook counters, launched flags, pending pushes, gradients; optionally the step counter."""
+        nb = len(self.layout.buckets)
+        for p in self.params:
+            p.grad = None
+        self._pending = [len(b.params) for b in self.layout.buckets]
+        self._launched = [False] * nb
+        self._pushed = [None] * nb
+        self._pull_pending = [False] * nb
+        if global_step is not None:
+            self.global_step = int(global_step)
+
     def flush(self):
         """Drain a stale-mode pipeline (end of training / before checkpoint): the newest pipeline's output
         holds every update."""
@@ -486,6 +622,12 @@ class ShardedPS:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._attached is not None:
+            for h in self._attached["handles"]:
+                h.remove()
+            self._attached = None
+            self._prefetch = False
+            self._join()
 
     def full_master(self):
         """All-gather the fp32 master weights (tests / export): flat [total]."""

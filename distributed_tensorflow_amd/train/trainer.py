@@ -136,16 +136,36 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
         if graph and dev.type == "cuda" and replay is None and it - start_step == 3:
             torch.cuda.synchronize(dev)
             time.sleep(0.5)             # the RCCL watchdog retires the earlier collectives (no event queries mid-capture)
+            if hasattr(ps, "disable_prefetch"):
+                ps.disable_prefetch()
+            step_before = ps.global_step
+            ok = torch.ones(1, device=dev)
+            g = None
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     static_loss = eager()
-                replay = g
-                ps.global_step -= 1     # the capture ran no kernels; the replay below is this step
-                print("[train] step captured in a hipGraph", flush=True)
             except Exception as e:      # noqa: BLE001 -- stay eager rather than fail the job
                 print("[train] hipGraph capture failed (%s); staying eager" % type(e).__name__, flush=True)
-                graph = False
+                ok.zero_()
+                torch.cuda.synchronize(dev)
+            comm = getattr(ps, "comm", None)
+            if comm is not None and comm.live and comm.world_size > 1:
+                # every rank replays or none does: a rank replaying captured collectives against ranks issuing
+                # them eagerly is legal, but a rank whose capture died midway must not be the only eager one
+                import torch.distributed as dist
+
+                comm.all_reduce(ok, op=dist.ReduceOp.MIN)
+            # the capture (complete or not) ran no kernel but moved the host-side bookkeeping of one step
+            if hasattr(ps, "reset_step_state"):
+                ps.reset_step_state(step_before)
+            else:
+                ps.global_step = step_before
+            if float(ok.item()) >= 1.0:
+                replay = g
+                print("[train] step captured in a hipGraph", flush=True)
+            else:
+                graph, static_loss = False, None
         if replay is not None:
             replay.replay()
             ps.global_step += 1
@@ -273,6 +293,8 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
         shards = num_ps if (opts.ps_shards == "spec" and num_ps >= 1) else None
         ps = ShardedPS(named, comm, opt, opts.bucket_mb, wire, "stale" if opts.update_mode == "stale" else "sync",
                        opts.push, num_shards=shards, staleness=opts.staleness)
+    if isinstance(ps, ShardedPS):
+        ps.attach(model)            # forward-order pull prefetch (eager, W > 1)
     print("[worker %d] PS runtime: %s, update_mode=%s, shard groups=%d, push=%s" % (
         task_index, type(ps).__name__, ps.update_mode, getattr(ps, "num_shards", num_ps), getattr(ps, "push", "-")),
         flush=True)

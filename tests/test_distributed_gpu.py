@@ -65,6 +65,40 @@ def test_bert_clipped_adam_through_rccl_single_rank(dev, rccl, push):
     ps2.remove_hooks()
 
 
+def test_forward_order_pull_prefetch_is_bitwise_the_global_join(dev, rccl):
+    """``ShardedPS.attach``: the next forward waits per bucket (forward pre-hooks on the owner modules, the
+    functionally-read embedding tables at the root) instead of joining the whole comm stream.  BERT's clipped path
+    applies + pulls in forward layer order.  Must leave bitwise what the joined path leaves, must really have
+    switched to per-bucket waits, and the root set must hold the bucket of ``word_embeddings`` (read by the root
+    module's own forward, never through ``nn.Embedding.forward``)."""
+    from distributed_tensorflow_amd.models import bert
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+
+    torch.manual_seed(0)
+    m1 = bert.prepare(bert.build(layers=2, hidden=256, heads=4, intermediate=1024, vocab=3000), dev)
+    m2 = copy.deepcopy(m1)
+    batch = bert.synthetic_batch(4, device=dev, seed=1, seq_len=128, vocab=3000)
+    opt = bert.default_optimizer()
+    ps1 = ShardedPS(list(m1.named_parameters()), rccl, opt, bucket_mb=1).attach(m1)
+    ps2 = ShardedPS(list(m2.named_parameters()), rccl, opt, bucket_mb=1)
+    assert ps1._attached is not None and len(ps1.layout.buckets) > 3
+    for it in range(5):
+        l1 = bert.loss_fn(m1, batch)
+        l1.backward()
+        ps1.step()
+        l2 = bert.loss_fn(m2, batch)
+        l2.backward()
+        ps2.step()
+        torch.cuda.synchronize()
+        assert torch.equal(l1, l2), it
+        assert torch.equal(ps1.param_flat, ps2.param_flat) and torch.equal(ps1.master, ps2.master), it
+    assert ps1._prefetch and ps1.prefetch_waits >= 3 * len(ps1.layout.buckets)
+    emb_bucket = ps1._slot_bucket[id(m1.word_embeddings.weight)]
+    assert emb_bucket in ps1._attached["root_buckets"]
+    ps1.remove_hooks()
+    ps2.remove_hooks()
+
+
 def test_stale2_through_rccl_single_rank(dev, rccl):
     from distributed_tensorflow_amd.models import resnet
     from distributed_tensorflow_amd.parallel.comm import Comm
