@@ -188,6 +188,12 @@ def main(argv=None):
     mode = str(opts.gemm_tuning).lower()
     if mode in ("on", "1", "true") or (mode == "auto" and opts.steps >= 10000):
         gemm_tuning.setup()
+    elif mode in ("off", "0", "false") and gemm_tuning.active():
+        # a GPU-hot warm worker resolved the shipped file while it was idle; this job asked for the defaults
+        import torch.cuda.tunable as tunable
+
+        tunable.enable(False)
+        gemm_tuning.deactivate()
     from ..train.trainer import run_task
 
     rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,
@@ -213,6 +219,9 @@ def leave(rc):
     try:
         sys.stdout.flush()
         sys.stderr.flush()
+        from ..utils import miopen as miopen_cache
+
+        miopen_cache.cleanup_tagged()       # a GPU-hot warm worker's pid-keyed MIOpen copy
     finally:
         os._exit(rc)
 

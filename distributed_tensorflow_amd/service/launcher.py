@@ -267,6 +267,108 @@ class _WarmPool:
                 pass
 
 
+class _HotPool:
+    """One GPU-HOT warm rank per free device (``service/warm_worker.py`` with ``DTF_WARM_HOT=1``): started with
+    ``HIP_VISIBLE_DEVICES`` already pinned to that device, HIP context up, kernel library / MIOpen / hipBLASLt
+    loaded.  ``take(g)`` hands out the worker of device ``g`` (None when it is not ready: the caller then starts the
+    task another way, and a worker still coming up on that device is stopped so the task is alone on it)."""
+
+    def __init__(self, python, env, root, warm_model=""):
+        self._python, self._env, self._root, self._model = python, dict(env), root, warm_model
+        self._lock = threading.Lock()
+        self._procs = {}        # gpu -> [Popen or None while spawning, ready, generation]
+        self._gen = 0
+        self._closed = False
+
+    def spawn(self, g):
+        with self._lock:
+            if self._closed or g in self._procs:
+                return
+            self._gen += 1
+            self._procs[g] = [None, False, self._gen]
+            gen = self._gen
+        threading.Thread(target=self._spawn, args=(g, gen), name="hot-spawn-%d" % g, daemon=True).start()
+
+    def _spawn(self, g, gen):
+        p = None
+        try:
+            env = dict(self._env)
+            env["PYTHONPATH"] = self._root + os.pathsep + env.get("PYTHONPATH", "")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.update(HIP_VISIBLE_DEVICES=str(g), DTF_WARM_HOT="1", DTF_NUM_GPUS="1")
+            if self._model:
+                env["DTF_WARM_MODEL"] = self._model
+            p = subprocess.Popen([self._python, "-u", "-m", "distributed_tensorflow_amd.service.warm_worker"], env=env,
+                                 stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                 start_new_session=True)
+            with self._lock:
+                cur = self._procs.get(g)
+                if cur is not None and cur[2] == gen:
+                    cur[0] = p
+            line = p.stdout.readline()          # "WARM <pid> HOT": device initialised, libraries loaded
+            if not line.startswith(b"WARM"):
+                raise RuntimeError("hot worker for GPU %d did not come up" % g)
+        except Exception:       # noqa: BLE001 -- no hot worker just means a colder start
+            log.exception("hot worker for GPU %d failed to start", g)
+            if p is not None:
+                p.kill()
+            with self._lock:
+                cur = self._procs.get(g)
+                if cur is not None and cur[2] == gen:
+                    self._procs.pop(g, None)
+            return
+        with self._lock:
+            cur = self._procs.get(g)
+            if cur is not None and cur[2] == gen and not self._closed:
+                cur[1] = True
+                p = None
+        if p is not None:       # discarded while it was starting
+            p.kill()
+
+    def is_ready(self, g):
+        with self._lock:
+            cur = self._procs.get(g)
+            return bool(cur and cur[1] and cur[0] is not None and cur[0].poll() is None)
+
+    def ready(self):
+        with self._lock:
+            return sorted(g for g, cur in self._procs.items() if cur[1] and cur[0].poll() is None)
+
+    def take(self, g):
+        """The ready worker of device ``g``, or None.  Either way the device has no hot worker afterwards."""
+        with self._lock:
+            cur = self._procs.pop(g, None)
+        if cur is None:
+            return None
+        p, ready, _ = cur
+        if p is not None and ready and p.poll() is None:
+            return p
+        if p is not None:
+            try:
+                p.kill()
+                p.wait(5)
+            except (OSError, subprocess.SubprocessError):
+                pass
+        return None
+
+    def discard(self, g):
+        p = self.take(g)
+        if p is not None:
+            try:
+                p.stdin.close()
+                p.kill()
+                p.wait(5)
+            except (OSError, subprocess.SubprocessError):
+                pass
+
+    def close(self):
+        with self._lock:
+            self._closed = True
+            gpus = list(self._procs)
+        for g in gpus:
+            self.discard(g)
+
+
 class LocalCluster:
     def __init__(self, gpus=None, log_dir=None, python=None, extra_env=None, cfg=None):
         cfg = cfg or ApiConfig()
@@ -297,15 +399,25 @@ class LocalCluster:
         # hipMemGetInfo "used" of every device while NO task holds it: what a reclaimed device must return to
         self._idle_used = {}
         self._verify = cfg.getboolean("launcher", "verify_reclaim", True) if self._all_gpus else False
-        self._sample_after = cfg.getfloat("launcher", "hbm_sample_after_seconds", 4.0)
-        if self._verify:
-            threading.Thread(target=self._probe_idle_baseline, name="hbm-baseline", daemon=True).start()
-        # warm rank pool: only for the framework's own entry module (a custom image starts cold)
+        self._sample_wait = cfg.getfloat("launcher", "hbm_sample_wait_seconds", 60.0)
+        # warm rank pools: only for the framework's own entry module (a custom image starts cold)
         n_warm = cfg.getint("launcher", "warm_pool", 0)
         self._root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         self._warm = None
-        if n_warm > 0 and cfg.get("image", "tensorflow") == ENTRY_IMAGE:
+        own_image = cfg.get("image", "tensorflow") == ENTRY_IMAGE
+        if n_warm > 0 and own_image:
             self._warm = _WarmPool(n_warm, self._python, dict(os.environ, **self._extra_env), self._root)
+        # GPU-hot ranks: one per free device, started AFTER the idle-device baseline has been probed (a hot rank
+        # holds a HIP context, i.e. HBM, on its device)
+        self._hot = None
+        if self._all_gpus and own_image and cfg.getboolean("launcher", "warm_gpu_pool", False):
+            self._hot = _HotPool(self._python, dict(os.environ, **self._extra_env), self._root,
+                                 cfg.get("launcher", "warm_model", ""))
+        if self._verify:
+            threading.Thread(target=self._probe_idle_baseline, name="hbm-baseline", daemon=True).start()
+        elif self._hot is not None:
+            for g in self._all_gpus:
+                self._hot.spawn(g)
 
     # ------------------------------------------------------------------ DNS
     def _alloc_port(self):
@@ -410,6 +522,11 @@ class LocalCluster:
                     # only trust a baseline measured while the device was still unassigned
                     if o["gpu"] in self._free_gpus:
                         self._idle_used.setdefault(o["gpu"], o["used"])
+        if self._hot is not None:
+            with self._lock:
+                free = list(self._free_gpus)
+            for g in free:
+                self._hot.spawn(g)
 
     @staticmethod
     def _gpu_request(body, resource_name):
@@ -443,7 +560,13 @@ class LocalCluster:
             need = t.requested_gpus if self._all_gpus else 0
             if need > len(self._free_gpus):
                 continue
-            t.gpus = [self._free_gpus.pop(0) for _ in range(need)]
+            if need == 1 and self._hot is not None:
+                # prefer a device whose GPU-hot rank is ready
+                g = next((g for g in self._free_gpus if self._hot.is_ready(g)), self._free_gpus[0])
+                self._free_gpus.remove(g)
+                t.gpus = [g]
+            else:
+                t.gpus = [self._free_gpus.pop(0) for _ in range(need)]
             try:
                 self._start(t)
             except Exception as e:  # spawn failure = failed job, not a dead service
@@ -479,7 +602,15 @@ class LocalCluster:
         env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
         os.makedirs(self._log_dir, exist_ok=True)
         t.log_path = os.path.join(self._log_dir, t.name + ".log")
-        warm = self._warm.take() if (self._warm is not None and image == ENTRY_IMAGE) else None
+        warm, hot = None, False
+        if self._hot is not None and t.gpus:
+            if image == ENTRY_IMAGE and len(t.gpus) == 1:
+                warm = self._hot.take(t.gpus[0])
+                hot = warm is not None
+            for g in t.gpus:
+                self._hot.discard(g)            # the task must be alone on its devices
+        if warm is None and self._warm is not None and image == ENTRY_IMAGE:
+            warm = self._warm.take()
         if warm is not None:
             # a pre-started process becomes the task: it only needs what differs from the launcher's own environment
             delta = {k: v for k, v in env.items() if os.environ.get(k) != v}
@@ -489,7 +620,7 @@ class LocalCluster:
                 warm.stdin.flush()
                 warm.stdin.close()
                 t.proc = warm
-                t.status["warm"] = True
+                t.status["warm"] = "hot" if hot else True
             except OSError:
                 warm.kill()
                 warm = None
@@ -514,10 +645,27 @@ class LocalCluster:
         if t.gpus and self._verify:
             used = hbm_used_bytes()
             t.hbm_before = {g: used[g] for g in t.gpus if g < len(used)} or None
-            try:
-                t.proc.wait(self._sample_after)
-            except subprocess.TimeoutExpired:
-                t.hbm_during = probe_hbm(t.gpus, self._python)       # one sample while the task holds the device
+            # one sample while the task holds the device -- taken once its log reports the first finished step (the
+            # model, optimizer state and activations are allocated by then: a sample at a fixed delay used to land
+            # before the allocation and read the idle value), else after hbm_sample_wait_seconds
+            t_end = time.time() + self._sample_wait
+            seen = False
+            while t.proc.poll() is None and time.time() < t_end and not seen:
+                try:
+                    with open(t.log_path, "rb") as f:
+                        seen = b"first step done" in f.read()
+                except OSError:
+                    pass
+                if not seen:
+                    try:
+                        t.proc.wait(max(0.01, min(0.25, t_end - time.time())))
+                    except subprocess.TimeoutExpired:
+                        pass
+            if t.proc.poll() is None:
+                t.hbm_during = probe_hbm(t.gpus, self._python)
+                if t.hbm_during:
+                    for d in t.hbm_during:
+                        d["after_first_step"] = seen
         rc = t.proc.wait()
         with self._lock:
             t.exit_code = rc
@@ -535,6 +683,14 @@ class LocalCluster:
             if not t.deleted:
                 self._release_gpus(t)
                 self._schedule()
+                self._respawn_hot(t)
+
+    def _respawn_hot(self, t):
+        # caller holds the lock: a released device that nobody took gets a fresh GPU-hot rank
+        if self._hot is not None and not self._closed:
+            for g in t.gpus:
+                if g in self._free_gpus:
+                    self._hot.spawn(g)
 
     def _deadline_exceeded(self, t):
         """activeDeadlineSeconds: a task still running past its deadline is killed and reported
@@ -663,6 +819,7 @@ class LocalCluster:
             t.status.update(active=0, phase="Deleted")
             self._emit("DELETED", t)
             self._schedule()
+            self._respawn_hot(t)
         return AttrDict.wrap({"status": "Success",
                               "details": {"name": name, "kind": "jobs", "signal": how, "hbm": rep}})
 
@@ -719,6 +876,8 @@ class LocalCluster:
             self._cv.notify_all()
         if self._warm is not None:
             self._warm.close()
+        if self._hot is not None:
+            self._hot.close()
         for t in tasks:
             t.deleted = True
             self._kill(t)

@@ -38,6 +38,12 @@ def active():
 _fwd_shapes = None
 
 
+def deactivate():
+    """The process stops using the shipped choices (``tunable.enable(False)`` is the caller's)."""
+    global _active, _fwd_shapes
+    _active, _fwd_shapes = False, None
+
+
 def _validator_ok(key, value):
     """The two validators that can be checked from Python without touching the libraries (the others are left to
     TunableOp itself)."""

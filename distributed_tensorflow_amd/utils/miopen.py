@@ -50,8 +50,10 @@ def setup(force=False):
         return None
     # one private copy per local rank: eight processes of one node otherwise share (and lock) one sqlite
     # kernel cache and one find-db file while they all start at once
-    rank = os.environ.get("DTF_JOB_NAME", "") + os.environ.get(
-        "DTF_TASK_INDEX", os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0")))
+    # DTF_MIOPEN_TAG: a GPU-hot warm worker (service/warm_worker.py) creates its MIOpen handle BEFORE it knows which
+    # task it will become, so its copy is keyed by its own pid instead of by a rank
+    rank = os.environ.get("DTF_MIOPEN_TAG") or (os.environ.get("DTF_JOB_NAME", "") + os.environ.get(
+        "DTF_TASK_INDEX", os.environ.get("RANK", os.environ.get("LOCAL_RANK", "0"))))
     base = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "dtf_miopen_%d_r%s" % (os.getuid(), rank))
     db, cache = os.path.join(base, "db"), os.path.join(base, "cache")
     try:
@@ -68,3 +70,11 @@ def setup(force=False):
     os.environ["MIOPEN_USER_DB_PATH"] = db
     os.environ["MIOPEN_CUSTOM_CACHE_DIR"] = cache
     return db
+
+
+def cleanup_tagged():
+    """Remove the private copy of a ``DTF_MIOPEN_TAG`` process (called when that process ends)."""
+    tag = os.environ.get("DTF_MIOPEN_TAG")
+    if tag:
+        base = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), "dtf_miopen_%d_r%s" % (os.getuid(), tag))
+        shutil.rmtree(base, ignore_errors=True)

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--placement", default="")
     ap.add_argument("--staleness", type=int, default=1)
     ap.add_argument("--warm", type=int, default=0, help="size of the launcher's warm rank pool (0 = cold starts)")
+    ap.add_argument("--hot", type=int, default=0, help="1: GPU-hot warm ranks (one per free device)")
+    ap.add_argument("--warm-model", default="", help='hot ranks also run this once, e.g. "resnet50?batch=256"')
     ap.add_argument("--cpu", action="store_true", help="CPU / gloo job (no amd.com/gpu request)")
     ap.add_argument("--extra", default="", help="extra query string for the job's file URI, e.g. image_size=64")
     ap.add_argument("--fault", default="")
@@ -50,6 +52,9 @@ def main():
 
     ApiConfig.override("launcher", "grace_seconds", "3")
     ApiConfig.override("launcher", "warm_pool", str(a.warm))
+    ApiConfig.override("launcher", "warm_gpu_pool", str(a.hot))
+    ApiConfig.override("launcher", "warm_model", a.warm_model)
+    os.environ.setdefault("DTF_TRACE_START", "1")        # the tasks log "[start +x s] <stage>" lines
     ngpu = 0 if a.cpu else visible_gpu_count()
     gpus = list(range(min(ngpu, a.workers))) if ngpu else []
     hbm0 = hbm_used_bytes()
@@ -66,6 +71,11 @@ def main():
         t_w = time.time()
         while not aio.cluster._idle_used and time.time() - t_w < 60:
             time.sleep(0.05)
+    if a.hot and gpus:
+        t_w = time.time()
+        while len(aio.cluster._hot.ready()) < len(gpus) and time.time() - t_w < 240:
+            time.sleep(0.05)
+        print("[submit] GPU-hot ranks ready on %s after %.1f s" % (aio.cluster._hot.ready(), time.time() - t_w), flush=True)
     q = "steps=%d&batch=%d&update_mode=%s&staleness=%d&log_every=10" % (a.steps, a.batch, a.update_mode, a.staleness)
     if a.placement:
         q += "&placement=" + a.placement
@@ -81,6 +91,7 @@ def main():
     uid = parse_task_name(names[0])[0]
     out = {"uid": uid, "tasks": names, "post_roundtrip_s": round(t_resp - t_post, 4), "model": a.model,
            "gpus": gpus, "workers": a.workers, "ps": a.ps, "update_mode": a.update_mode, "warm_pool": a.warm,
+           "gpu_hot_pool": a.hot, "warm_model": a.warm_model,
            "batch": a.batch, "force_comm": os.environ.get("DTF_FORCE_COMM", "0"),
            "idle_baseline_mb": {g: u >> 20 for g, u in aio.cluster._idle_used.items()}}
     if any(hbm0):
@@ -121,7 +132,21 @@ def main():
             out[k] = m[k]
     if "t_cleaned" in rec:
         out["submit_to_cleaned_s"] = round(float(rec["t_cleaned"]) - float(m.get("t_submit", t_post)), 3)
-    out["hbm_reclaim"] = rec.get("hbm_reclaim") or aio.cluster.reclaim_reports
+    # the reclaim probe of a task that ended by itself runs in its waiter thread AFTER the status event: wait for it
+    n_gpu_tasks = len(gpus) if gpus else 0
+    t_w = time.time()
+    while len(aio.cluster.reclaim_reports) < n_gpu_tasks and time.time() - t_w < 60:
+        time.sleep(0.1)
+    out["hbm_reclaim"] = list(aio.cluster.reclaim_reports) or rec.get("hbm_reclaim") or []
+    # start-up anatomy of the chief ("[start +x s] stage" lines, DTF_TRACE_START=1) and what a hot rank had warmed
+    try:
+        chief = [n for n in names if "-worker-0-" in n][0]
+        with open(os.path.join("gpurun_out", "tasks", chief + ".log"), errors="replace") as f:
+            lines = f.read().splitlines()
+        out["chief_start_trace"] = [ln for ln in lines if ln.startswith("[start +") or ln.startswith("[warm]")
+                                    or "first step done" in ln]
+    except (OSError, IndexError):
+        pass
     time.sleep(0.5)
     hb = hbm_used_bytes()
     if any(hb):

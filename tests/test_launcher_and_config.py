@@ -53,7 +53,7 @@ def probing_cluster(tmp_path, monkeypatch):
     ApiConfig.override("image", "tensorflow", "tests.fake_task")
     ApiConfig.override("launcher", "grace_seconds", "0.3")
     ApiConfig.override("launcher", "verify_reclaim", "1")
-    ApiConfig.override("launcher", "hbm_sample_after_seconds", "0.2")
+    ApiConfig.override("launcher", "hbm_sample_wait_seconds", "0.2")
     c = LocalCluster(gpus=[0, 1], log_dir=str(tmp_path), extra_env={"PYTHONPATH": ROOT})
     c.probe_calls = calls
     yield c
@@ -342,3 +342,38 @@ def test_tuned_gemm_shapes_drive_the_conv1x1_library_choice(tmp_path, monkeypatc
     assert not conv._mm_fwd(torch.empty(256, 256, 56, 56, device="meta"), w_256)        # 256 input channels: MIOpen measured faster
     monkeypatch.setenv("PYTORCH_TUNABLEOP_ENABLED", "0")
     assert gemm_tuning.tuned_gemm_shapes() == frozenset()
+
+
+def test_gpu_hot_pool_hands_the_device_its_own_rank_and_respawns(tmp_path):
+    """GPU-hot ranks: one pre-started rank per free device, pinned with HIP_VISIBLE_DEVICES; a
+    1-GPU task adopts the rank of the device it was scheduled on, nobody else stays on that device, and the device
+    gets a fresh rank once it is released.  (No device here: the rank skips the HIP part, the plumbing is the same.)"""
+    from distributed_tensorflow_amd.service.launcher import ENTRY_IMAGE, LocalCluster
+    from distributed_tensorflow_amd.service.manifest import gen_job
+
+    ApiConfig.override("image", "tensorflow", ENTRY_IMAGE)
+    ApiConfig.override("launcher", "verify_reclaim", "0")
+    ApiConfig.override("launcher", "warm_gpu_pool", "1")
+    try:
+        c = LocalCluster(gpus=[0, 1], log_dir=str(tmp_path), extra_env={"PYTHONPATH": ROOT})
+        assert c._hot is not None
+        assert _wait(lambda: c._hot.ready() == [0, 1], 120), c._hot.ready()
+        uid = "3e8f3702-d10b-11e8-abe4-fa163ef8da8a"
+        info = {"file": "builtin://mnist_mlp?steps=3&batch=8&log_every=1", "resource": {"gpu": 1},
+                "detail": {"ps": 0, "worker": 1}}
+        body = gen_job(uid, "worker", 0, 1, info, "", "tf-%s-worker-0-1:2222" % uid)
+        j = c.create_namespaced_job("default", body)
+        name = j["metadata"]["name"]
+        st = c.read_namespaced_job(name, "default")["status"]
+        assert st["warm"] == "hot" and st["gpus"] == [0]
+        assert 0 not in c._hot.ready()                      # the device's rank became the task
+        assert _wait(lambda: c.read_namespaced_job(name, "default")["status"]["succeeded"] == 1, 120), \
+            open(os.path.join(str(tmp_path), name + ".log")).read()
+        log_text = open(os.path.join(str(tmp_path), name + ".log")).read()
+        assert "GPU-hot" in log_text and "done: 3 steps" in log_text
+        assert _wait(lambda: c._hot.ready() == [0, 1], 120)   # respawned after the release
+    finally:
+        c.shutdown()
+        ApiConfig.override("launcher", "warm_gpu_pool", "0")
+        ApiConfig.override("launcher", "verify_reclaim", "1")
+        ApiConfig.override("image", "tensorflow", "tests.fake_task")
