@@ -56,7 +56,8 @@ def main():
                     help="1: capture the whole step (forward, backward, hook-launched PS pipeline incl. its RCCL "
                          "collectives) in one hipGraph and replay it, any N, with automatic fallback to eager when the "
                          "capture fails on any rank; 0: eager; -1 (default): 1 on one GPU (validated bitwise equal to "
-                         "eager there), 0 on several")
+                         "eager there) IF a short timed trial in the warm-up phase finds the replay faster than the eager "
+                         "loop, 0 on several")
     ap.add_argument("--lr-warmup-steps", type=int, default=100,
                     help="gradual warm-up (Goyal et al.): lr = peak * min(1, step / N); 0: constant peak lr")
     ap.add_argument("--profile-dir", default="")
@@ -143,7 +144,8 @@ def main():
     if "seq_len" in kw:
         bkw["seq_len"] = int(kw["seq_len"])
     batch = mod.synthetic_batch(a.batch, device=dev, seed=100 + comm.rank, **bkw)
-    if a.graph < 0:
+    graph_auto = a.graph < 0
+    if graph_auto:
         a.graph = 1 if (on_gpu and comm.world_size == 1 and a.update_mode != "async") else 0
 
     # lr schedule: the learning rate lives in device memory (ps.hyper), so a captured graph replays with new values
@@ -200,16 +202,37 @@ def main():
             ok.zero_()
             torch.cuda.synchronize()
         if comm.world_size > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank replays, or none does
+            comm.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank replays, or none does
         if float(ok.item()) < 1.0:
             graph = None
+        graph_trial = None
         if graph is not None:
             eager_step = step
 
-            def step():  # noqa: F811
+            def graph_step():
                 next_lr()
                 graph.replay()
                 return static_loss
+
+            if graph_auto:
+                # which is faster HERE?  A replay costs the host one call instead of ~550 launches, but the step is
+                # GPU-bound on one MI355X and the graph's per-node dispatch measured 0.5-1.5 % SLOWER than a full
+                # eager queue (profiles/r3_graph_vs_eager.txt).  Six timed steps each way, untimed for the result.
+                def trial(fn, n=6):
+                    fn()
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    for _ in range(n):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t_) / n
+
+                te, tg = trial(eager_step), trial(graph_step)
+                graph_trial = {"eager_ms": round(te * 1e3, 3), "graph_ms": round(tg * 1e3, 3)}
+                if tg > te * 0.998:
+                    graph = None            # eager is at least as fast: stay eager
+            if graph is not None:
+                step = graph_step  # noqa: F811
     t_w = time.perf_counter()
     for i in range(a.warmup):
         loss = step()
@@ -241,7 +264,7 @@ def main():
     t_probe = sorted(probe)[1]
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if comm.world_size > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     last_loss = float(loss.detach().float().item())
     n = comm.world_size
@@ -261,7 +284,8 @@ def main():
                        "pull": "all_gather" if ps.family == "scatter" else "broadcast", "staleness": ps.staleness,
                        "wire_dtype": str(ps.wire_dtype).replace("torch.", ""),
                        "update_mode": a.update_mode, "optimizer": opt.kind, "bucket_mb": a.bucket_mb,
-                       "hipgraph": bool(graph is not None), "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db), "gemm_shipped_db": bool(gemm_db),
+                       "comm_backend": str(comm.backend),
+                       "hipgraph": bool(graph is not None), "hipgraph_trial": graph_trial if a.graph and on_gpu else None, "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db), "gemm_shipped_db": bool(gemm_db),
                        "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),
                        "host_enqueue_ms_per_step": round(t_probe * 1e3, 3),
                        "host_loop_ms_per_step": round(t_host / a.steps * 1e3, 3),

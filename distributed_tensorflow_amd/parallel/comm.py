@@ -57,6 +57,11 @@ class Comm:
             torch.cuda.set_device(device)
         if world == 1 and not force:
             return cls(0, 1, device)
+        if backend == "rccl-native":
+            # direct RCCL calls on the caller's stream (native/rccl_comm.cpp): no c10d Work objects, no watchdog
+            from .rccl_native import NativeComm
+
+            return NativeComm.from_env(device, timeout_s)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")

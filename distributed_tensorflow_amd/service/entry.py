@@ -102,9 +102,9 @@ def main(argv=None):
     # /root/reference/handlers/train_handler.py:80-83): fetched through the WebHDFS gateway into a task-private
     # directory before anything runs; an hdfs:// `export` is produced locally and uploaded when the task ends
     hdfs_web = argv[7]
-    export_remote = None
     from ..utils import hdfs
 
+    stage, sync = None, None
     if hdfs.is_remote(file_field) or hdfs.is_remote(data_dir) or hdfs.is_remote(export_dir):
         import tempfile
 
@@ -112,24 +112,59 @@ def main(argv=None):
         try:
             file_field = hdfs.localize(file_field, os.path.join(stage, "file"), hdfs_web)
             data_dir = hdfs.localize(data_dir, os.path.join(stage, "data"), hdfs_web)
+            if hdfs.is_remote(export_dir):
+                remote = hdfs.split(export_dir)[1]
+                export_dir = os.path.join(stage, "export")
+                os.makedirs(export_dir, exist_ok=True)
+                sync = hdfs.ExportSync(hdfs.client_from(hdfs_web), export_dir, remote)
         except hdfs.HdfsError as e:
             print("[entry] %s" % e, file=sys.stderr, flush=True)
+            _rmtree(stage)
             return 2
-        if hdfs.is_remote(export_dir):
-            export_remote, export_dir = hdfs.split(export_dir)[1], os.path.join(stage, "export")
-            os.makedirs(export_dir, exist_ok=True)
         argv[4], argv[5], argv[6] = file_field, data_dir, export_dir
         print("[entry] hdfs fields staged under %s" % stage, flush=True)
+    try:
+        return _main_staged(t_start, argv, job_name, task_index, ps_csv, worker_csv, file_field, data_dir, export_dir,
+                            ps_hosts, worker_hosts, dns, task_name, uid, sync)
+    finally:
+        # the stage directory (localized file / data copies, the export mirror) lives exactly as long as the task
+        _rmtree(stage)
 
-    def upload_export():
-        if export_remote and os.path.isdir(export_dir) and os.listdir(export_dir):
-            try:
-                hdfs.client_from(hdfs_web).put(export_dir, export_remote)
-                print("[entry] export uploaded to hdfs:%s" % export_remote, flush=True)
-            except hdfs.HdfsError as e:
-                print("[entry] export upload failed: %s" % e, file=sys.stderr, flush=True)
-                return 1
+
+def _rmtree(path):
+    if path:
+        import shutil
+
+        shutil.rmtree(path, ignore_errors=True)
+
+
+def _main_staged(t_start, argv, job_name, task_index, ps_csv, worker_csv, file_field, data_dir, export_dir,
+                 ps_hosts, worker_hosts, dns, task_name, uid, sync):
+    from ..utils import hdfs
+
+    def upload_export(publish=True):
+        """Mirror the export directory to hdfs:// (no-op for a local export).  -> 0 / 1."""
+        if sync is None:
+            return 0
+        try:
+            sent = sync.push(publish=publish)
+            if sent:
+                print("[entry] export -> hdfs:%s: %s" % (sync.remote, ", ".join(sent)), flush=True)
+        except hdfs.HdfsError as e:
+            print("[entry] export upload failed: %s" % e, file=sys.stderr, flush=True)
+            return 1
         return 0
+
+    def on_checkpoint(step, comm, chief):
+        """Called by the trainer on EVERY rank after a checkpoint is on local disk: data first, everybody; then --
+        after a barrier -- the chief publishes index + pointer."""
+        if sync is None:
+            return
+        upload_export(publish=False)
+        if comm is not None:
+            comm.barrier()
+        if chief:
+            upload_export(publish=True)
 
     from ..train.jobspec import parse_file_field
 
@@ -154,8 +189,11 @@ def main(argv=None):
         import runpy
 
         sys.argv = [spec] + argv
-        runpy.run_path(spec, run_name="__main__")
-        return upload_export()
+        try:
+            runpy.run_path(spec, run_name="__main__")
+        finally:
+            upload_export()         # whatever the script exported, also when it raised
+        return 0
 
     opts = spec
     P, W = len(ps_hosts), len(worker_hosts)
@@ -196,10 +234,26 @@ def main(argv=None):
         gemm_tuning.deactivate()
     from ..train.trainer import run_task
 
-    rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,
-                  opts=opts, data_dir=data_dir, export_dir=export_dir, metrics=put, t_start=t_start)
-    if rc == 0:
-        rc = upload_export()
+    if sync is not None and opts.resume:
+        # resume from a remote export: the stage directory starts empty -- bring the latest checkpoint in first
+        try:
+            got = sync.fetch_latest()
+            print("[entry] resume: %s" % ("fetched checkpoint step %s from hdfs:%s" % (got, sync.remote)
+                                          if got is not None else "no checkpoint under hdfs:%s" % sync.remote), flush=True)
+        except hdfs.HdfsError as e:
+            print("[entry] resume: could not fetch the remote checkpoint: %s" % e, file=sys.stderr, flush=True)
+            return 2
+    rc = 1
+    try:
+        rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,
+                      opts=opts, data_dir=data_dir, export_dir=export_dir, metrics=put, t_start=t_start,
+                      on_checkpoint=on_checkpoint)
+    finally:
+        # also on failure: checkpoints of a run that died are the ones somebody will want.  A failed task does not
+        # publish a NEW pointer (it may be ahead of peers that never wrote their shard); data files still go up.
+        up = upload_export(publish=(rc == 0 and job_name == "worker" and task_index == 0))
+        if rc == 0:
+            rc = up
     if job_name == "ps":
         print("[entry] ps task finished serving; joining forever (waiting to be reaped)", flush=True)
         ps_join_forever()

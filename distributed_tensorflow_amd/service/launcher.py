@@ -277,6 +277,7 @@ class _HotPool:
         self._python, self._env, self._root, self._model = python, dict(env), root, warm_model
         self._lock = threading.Lock()
         self._procs = {}        # gpu -> [Popen or None while spawning, ready, generation]
+        self._hint = ""         # warm_model = auto: what the last built-in GPU job on this node trained
         self._gen = 0
         self._closed = False
 
@@ -296,8 +297,10 @@ class _HotPool:
             env["PYTHONPATH"] = self._root + os.pathsep + env.get("PYTHONPATH", "")
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             env.update(HIP_VISIBLE_DEVICES=str(g), DTF_WARM_HOT="1", DTF_NUM_GPUS="1")
-            if self._model:
+            if self._model and self._model != "auto":
                 env["DTF_WARM_MODEL"] = self._model
+            elif self._model == "auto" and self._hint:
+                env["DTF_WARM_MODEL"] = self._hint
             p = subprocess.Popen([self._python, "-u", "-m", "distributed_tensorflow_amd.service.warm_worker"], env=env,
                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                                  start_new_session=True)
@@ -324,6 +327,20 @@ class _HotPool:
                 p = None
         if p is not None:       # discarded while it was starting
             p.kill()
+
+    def observe(self, file_field):
+        """``warm_model = auto``: remember the model / batch / shape options of the job that just started; the ranks
+        spawned from now on run that once while idle (a node mostly re-runs the model family it ran last)."""
+        if self._model != "auto" or not str(file_field).startswith("builtin://"):
+            return
+        try:
+            from ..train.jobspec import parse_file_field
+
+            _, opts = parse_file_field(file_field)
+            q = ["batch=%d" % opts.batch] + ["%s=%s" % kv for kv in sorted(opts.extra.items())]
+            self._hint = "%s?%s" % (opts.model, "&".join(q))
+        except Exception:       # noqa: BLE001 -- a hint is an optimisation
+            pass
 
     def is_ready(self, g):
         with self._lock:
@@ -603,6 +620,8 @@ class LocalCluster:
         os.makedirs(self._log_dir, exist_ok=True)
         t.log_path = os.path.join(self._log_dir, t.name + ".log")
         warm, hot = None, False
+        if self._hot is not None and t.gpus and image == ENTRY_IMAGE and len(args) > 4:
+            self._hot.observe(args[4])
         if self._hot is not None and t.gpus:
             if image == ENTRY_IMAGE and len(t.gpus) == 1:
                 warm = self._hot.take(t.gpus[0])
@@ -667,6 +686,7 @@ class LocalCluster:
                     for d in t.hbm_during:
                         d["after_first_step"] = seen
         rc = t.proc.wait()
+        self._sweep_stage(t)
         with self._lock:
             t.exit_code = rc
             if t.deleted:
@@ -691,6 +711,16 @@ class LocalCluster:
             for g in t.gpus:
                 if g in self._free_gpus:
                     self._hot.spawn(g)
+
+    @staticmethod
+    def _sweep_stage(t):
+        """A task removes its hdfs:// stage directory (``entry.py``) itself -- unless it was killed.  The launcher
+        sweeps what a dead task left: ``<tmp>/dtf_hdfs_<task name>_*``."""
+        import shutil
+        import tempfile
+
+        for d in glob.glob(os.path.join(tempfile.gettempdir(), "dtf_hdfs_%s_*" % t.name)):
+            shutil.rmtree(d, ignore_errors=True)
 
     def _deadline_exceeded(self, t):
         """activeDeadlineSeconds: a task still running past its deadline is killed and reported
@@ -811,6 +841,7 @@ class LocalCluster:
         if already:
             raise ApiException(409, "job %s is already being deleted" % name)
         how = self._kill(t)
+        self._sweep_stage(t)
         # a task that ended on its own has been verified by its waiter thread already
         rep = self._verify_reclaim(t) if (self._verify and not released and t.gpus) else None
         with self._lock:

@@ -189,7 +189,7 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
 
 
 def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_dir, export_dir, metrics,
-             t_start=None):
+             t_start=None, on_checkpoint=None):
     """One task of a job, from rendezvous to teardown.  Whatever way the body ends -- worker done, ps task done
     serving, exception -- the process group is destroyed before the caller gets control back: a task that leaves
     the interpreter with a live gloo / RCCL group aborts in ``std::terminate`` and turns a finished job into a
@@ -198,7 +198,7 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
     ok = False
     try:
         rc = _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_dir, export_dir, metrics,
-                       t_start, comms)
+                       t_start, comms, on_checkpoint or (lambda step, comm, chief: None))
         ok = rc == 0
         return rc
     finally:
@@ -209,7 +209,9 @@ def run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_di
 
 
 def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_dir, export_dir, metrics,
-              t_start, comms):
+              t_start, comms, on_checkpoint):
+    """``on_checkpoint(step, comm, chief)`` runs on every rank once a checkpoint is complete on local disk
+    (``service/entry.py`` mirrors it to an ``hdfs://`` export there)."""
     t_start = t_start or time.time()
     trace = os.environ.get("DTF_TRACE_START", "0") == "1"
 
@@ -268,6 +270,7 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
                 sec[names[1]] = srv.slot_v
             ckpt.write_shard(export, steps, task_index, num_ps, sec)
             print("[ps %d] wrote checkpoint shard" % task_index, flush=True)
+            on_checkpoint(steps, None, False)       # the shard is (remotely) in place before the barrier below
         # shards first, index second: the chief publishes the index + 'checkpoint' pointer only after every PS task
         # has passed this barrier, so a reader that follows the pointer always finds the data files
         comm.barrier()
@@ -323,6 +326,7 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
                 print("[worker 0] first step done %.3f s after task start" % (now - t_start), flush=True)
         if opts.ckpt_every and do_ckpt and step % opts.ckpt_every == 0 and placement != "dedicated":
             save_checkpoint(model, ps, export, step, tf_names, chief)
+            on_checkpoint(step, comm, chief)
 
     remaining = max(0, opts.steps - start_step)
     items = opts.batch * num_workers
@@ -342,11 +346,13 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
             ckpt.write_replicated(export, applies, replicated_state(model, ps, applies))
             ckpt.write_index(export, applies, num_ps, variables, extra={"optimizer": opt.kind,
                                                                          "placement": "dedicated"})
+            on_checkpoint(applies, None, True)
     else:
         if one_sided:
             ps.finish()         # every worker's last apply has landed
         if do_ckpt:
             save_checkpoint(model, ps, export, ps.global_step, tf_names, chief)
+            on_checkpoint(ps.global_step, comm, chief)
         if one_sided:
             ps.close()
     if chief:

@@ -61,10 +61,12 @@ class WebHdfs:
         q.update(params)
         return self.base + urllib.parse.quote(path) + "?" + urllib.parse.urlencode(q)
 
-    def _open(self, url, method="GET", data=None, redirect=True):
+    def _open(self, url, method="GET", data=None, redirect=True, length=None):
         req = urllib.request.Request(url, data=data, method=method)
         if data is not None:
             req.add_header("Content-Type", "application/octet-stream")
+        if length is not None:
+            req.add_header("Content-Length", str(int(length)))
         opener = urllib.request.build_opener() if redirect else urllib.request.build_opener(_NoRedirect)
         try:
             return opener.open(req, timeout=self.timeout)
@@ -99,16 +101,25 @@ class WebHdfs:
         os.replace(tmp, dest)
         return dest
 
+    @staticmethod
+    def _safe_name(name, what):
+        """A directory entry reported by the gateway becomes a LOCAL file name: it must be one path component.
+        ``..`` or a name with a separator would let a gateway write outside the task's stage directory."""
+        if not name or name in (".", "..") or "/" in name or "\\" in name or "\0" in name:
+            raise HdfsError("refusing %s %r from the WebHDFS gateway: not a plain file name" % (what, name))
+        return name
+
     def get(self, path, dest_dir):
         """File -> ``dest_dir/<basename>``; directory -> ``dest_dir/<basename>/...`` (recursive).  Returns the local path."""
         st = self.status(path)
         if st is None:
             raise HdfsError("hdfs path %s does not exist" % path)
-        local = os.path.join(dest_dir, os.path.basename(path.rstrip("/")) or "root")
+        base = os.path.basename(path.rstrip("/"))
+        local = os.path.join(dest_dir, self._safe_name(base, "path") if base else "root")
         if st.get("type") == "DIRECTORY":
             os.makedirs(local, exist_ok=True)
             for ent in self.listdir(path):
-                self.get(path.rstrip("/") + "/" + ent["pathSuffix"], local)
+                self.get(path.rstrip("/") + "/" + self._safe_name(ent.get("pathSuffix", ""), "pathSuffix"), local)
             return local
         return self.get_file(path, local)
 
@@ -123,11 +134,12 @@ class WebHdfs:
             first.close()
         if not loc:          # a gateway that takes the data in one step (HttpFS with data=true) answers 201 directly
             loc = self._url(path, "CREATE", overwrite="true", data="true")
+        # the body is streamed from the file (checkpoint shards are multi-GB): urllib sends a file object in blocks
+        # when Content-Length is given
         with open(local, "rb") as f:
-            data = f.read()
-        with self._open(loc, "PUT", data=data) as r:
-            if r.status not in (200, 201):
-                raise HdfsError("WebHDFS CREATE %s -> HTTP %d" % (path, r.status))
+            with self._open(loc, "PUT", data=f, length=os.path.getsize(local)) as r:
+                if r.status not in (200, 201):
+                    raise HdfsError("WebHDFS CREATE %s -> HTTP %d" % (path, r.status))
         return path
 
     def put(self, local, path):
@@ -138,6 +150,76 @@ class WebHdfs:
                 self.put(os.path.join(local, name), path.rstrip("/") + "/" + name)
             return path
         return self.put_file(local, path)
+
+
+class ExportSync:
+    """A task's local ``export`` directory mirrored to ``hdfs://`` (``entry.py``).
+
+    * :meth:`fetch_latest` (before training, when the job resumes): the remote ``checkpoint`` pointer and every file
+      of the step it names -- without this a resumed job would look at an empty stage directory and start over;
+    * :meth:`push` after EVERY checkpoint and once more when the task ends, whatever its exit code (mid-run
+      checkpoints exist for the runs that die): data files first, then -- ``publish=True``, the chief after a
+      barrier -- the index and the pointer, so a reader that follows the pointer always finds the shards."""
+
+    POINTER = "checkpoint"
+
+    def __init__(self, client, local_dir, remote_dir):
+        self.client, self.local, self.remote = client, local_dir, remote_dir.rstrip("/") or "/"
+        self._sent = {}
+        self._made = False
+
+    def fetch_latest(self):
+        """-> step fetched, or None when the remote export holds no checkpoint."""
+        ptr = self.remote + "/" + self.POINTER
+        if self.client.status(ptr) is None:
+            return None
+        os.makedirs(self.local, exist_ok=True)
+        self.client.get_file(ptr, os.path.join(self.local, self.POINTER))
+        prefix = None
+        with open(os.path.join(self.local, self.POINTER)) as f:
+            for line in f:
+                if line.startswith("model_checkpoint_path") and '"' in line:
+                    prefix = line.split('"')[1]
+        if not prefix:
+            return None
+        prefix = WebHdfs._safe_name(prefix, "checkpoint prefix")
+        for ent in self.client.listdir(self.remote):
+            name = WebHdfs._safe_name(ent.get("pathSuffix", ""), "pathSuffix")
+            if ent.get("type") == "FILE" and name.startswith(prefix + "."):
+                dst = os.path.join(self.local, name)
+                self.client.get_file(self.remote + "/" + name, dst)
+                st = os.stat(dst)
+                self._sent[name] = (st.st_mtime_ns, st.st_size)       # already remote: do not send it back
+        st = os.stat(os.path.join(self.local, self.POINTER))
+        self._sent[self.POINTER] = (st.st_mtime_ns, st.st_size)
+        return int(prefix.rsplit("-", 1)[1]) if "-" in prefix else None
+
+    def _is_publish_file(self, name):
+        return name == self.POINTER or name.endswith(".index")
+
+    def push(self, publish=False):
+        """Upload what changed since the last call.  ``publish=False``: everything but index + pointer."""
+        if not os.path.isdir(self.local):
+            return []
+        names = sorted(n for n in os.listdir(self.local) if os.path.isfile(os.path.join(self.local, n)))
+        # data, replicated state, then the index, the pointer last
+        order = [n for n in names if not self._is_publish_file(n)]
+        if publish:
+            order += [n for n in names if n.endswith(".index")] + [n for n in names if n == self.POINTER]
+        done = []
+        for n in order:
+            p = os.path.join(self.local, n)
+            st = os.stat(p)
+            sig = (st.st_mtime_ns, st.st_size)
+            if self._sent.get(n) == sig:
+                continue
+            if not self._made:
+                self.client.mkdirs(self.remote)
+                self._made = True
+            self.client.put_file(p, self.remote + "/" + n)
+            self._sent[n] = sig
+            done.append(n)
+        return done
 
 
 def client_from(web=None, user=None, cfg=None):

@@ -316,7 +316,8 @@ def main():
     # same cases run through real collectives on a one-GPU box.  Default: CPU over gloo.
     if os.environ.get("DTF_TEST_DEVICE", "cpu") == "cuda" and not case.startswith("async"):
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-        comm = Comm.from_env(device, backend="nccl", force=True)
+        # DTF_TEST_COMM=rccl-native: direct RCCL calls (native/rccl_comm.cpp) instead of torch.distributed
+        comm = Comm.from_env(device, backend=os.environ.get("DTF_TEST_COMM", "nccl"), force=True)
     else:
         device = torch.device("cpu")
         comm = Comm.from_env(device, backend="gloo")

@@ -165,3 +165,72 @@ def test_task_entry_fetches_file_and_data_and_uploads_export(gateway, tmp_path):
                         "hdfs://nn/jobs/absent.py", "/tmp", "/tmp", gateway, "hdfs://nn"],
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "does not exist" in r.stderr
+
+
+def test_gateway_supplied_names_cannot_escape_the_stage_directory(gateway, tmp_path):
+    """``pathSuffix`` comes from the gateway and becomes a local file name.  ``..`` / names with a
+    separator are refused instead of being joined into a path outside the destination."""
+    c = hdfs.WebHdfs(gateway)
+    for bad in ("..", "../evil", "a/b", ""):
+        with pytest.raises(hdfs.HdfsError):
+            hdfs.WebHdfs._safe_name(bad, "pathSuffix")
+
+    class Evil(hdfs.WebHdfs):
+        def listdir(self, path):
+            return [{"pathSuffix": "../../escaped.txt", "type": "FILE"}]
+
+    e = Evil(gateway)
+    with pytest.raises(hdfs.HdfsError):
+        e.get("/data/set1", str(tmp_path / "stage"))
+    assert not (tmp_path / "escaped.txt").exists()
+    assert c.get("/data/set1", str(tmp_path / "ok"))
+
+
+def test_put_streams_the_file_with_a_content_length(gateway, tmp_path):
+    big = tmp_path / "shard.bin"
+    big.write_bytes(os.urandom(3 << 20))
+    c = hdfs.WebHdfs(gateway)
+    c.mkdirs("/ck")
+    c.put_file(str(big), "/ck/shard.bin")
+    assert FakeHdfs.files["/ck/shard.bin"] == big.read_bytes()
+
+
+def _entry(gateway, argv_file, export, task="tf-3e8f3702-d10b-11e8-abe4-fa163ef8da8a-worker-0-1", extra_env=None):
+    env = dict(os.environ, PYTHONPATH=ROOT, DTF_TASK_NAME=task, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, "-m", "distributed_tensorflow_amd.service.entry", "worker", "0", "",
+                           "127.0.0.1:29518", argv_file, "/tmp", export, gateway, "hdfs://nn"],
+                          env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_remote_export_checkpoints_during_the_run_resume_and_failure(gateway, tmp_path):
+    """ADVICE r2: (a) every ``ckpt_every`` checkpoint reaches hdfs:// while the job runs -- data files before the
+    index and the pointer; (b) a task that FAILS still leaves its earlier checkpoints remote; (c) ``resume=1`` with a
+    remote export first fetches the latest checkpoint; (d) the stage directory is gone when the task ends."""
+    import glob
+    import tempfile
+
+    stage_glob = os.path.join(tempfile.gettempdir(), "dtf_hdfs_tf-3e8f3702*")
+    # a run that checkpoints at 4 and 8 and dies (injected exception) at step 10
+    r = _entry(gateway, "builtin://mnist_mlp?steps=12&batch=16&ckpt_every=4&log_every=4&fault=raise:worker=0,step=10",
+               "hdfs://nn/exp/runA")
+    assert r.returncode == 1 and "injected fault" in r.stderr, r.stdout + r.stderr
+    names = sorted(p[len("/exp/runA/"):] for p in FakeHdfs.files if p.startswith("/exp/runA/"))
+    assert "checkpoint" in names and "model.ckpt-8.index" in names and "model.ckpt-4.index" in names, names
+    assert any(n.startswith("model.ckpt-8.data-") for n in names), names
+    assert b"model.ckpt-8" in FakeHdfs.files["/exp/runA/checkpoint"]
+    puts = [e[2] for e in FakeHdfs.log if e[0] == "PUT" and e[1] == "CREATE" and e[4]]
+    i_data = max(i for i, p in enumerate(puts) if p.endswith("model.ckpt-8.data-00000-of-00001"))
+    i_index = max(i for i, p in enumerate(puts) if p.endswith("model.ckpt-8.index"))
+    i_ptr = max(i for i, p in enumerate(puts) if p.endswith("/checkpoint"))
+    assert i_data < i_index < i_ptr, puts
+    assert glob.glob(stage_glob) == [], "stage directory leaked"
+    # the same export, resumed: starts from step 8, finishes at 12
+    r = _entry(gateway, "builtin://mnist_mlp?steps=12&batch=16&ckpt_every=4&log_every=4&resume=1", "hdfs://nn/exp/runA")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "fetched checkpoint step 8" in r.stdout and "resumed from step 8" in r.stdout, r.stdout
+    assert b"model.ckpt-12" in FakeHdfs.files["/exp/runA/checkpoint"]
+    assert glob.glob(stage_glob) == []
+    # resume against an empty remote export starts from scratch, cleanly
+    r = _entry(gateway, "builtin://mnist_mlp?steps=4&batch=16&resume=1", "hdfs://nn/exp/fresh")
+    assert r.returncode == 0 and "no checkpoint under hdfs:/exp/fresh" in r.stdout, r.stdout + r.stderr

@@ -33,14 +33,14 @@ def _need(world):
         pytest.skip("needs %d GPUs, this box has %d" % (world, n))
 
 
-def run_gpu_ranks(world, case, out_dir, timeout=420):
+def run_gpu_ranks(world, case, out_dir, timeout=420, backend="nccl"):
     os.makedirs(out_dir, exist_ok=True)
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), DTF_TEST_DEVICE="cuda", HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   OMP_NUM_THREADS="2")
+                   OMP_NUM_THREADS="2", DTF_TEST_COMM=backend)
         procs.append(subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "dist_worker.py"), case, str(out_dir)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -75,6 +75,24 @@ def test_sharded_ps_on_gpus_equals_single_process(tmp_path, case, world):
     for n, p in ref.items():
         torch.testing.assert_close(res["params"][n], p, rtol=5e-4, atol=5e-5, msg=lambda m: "%s: %s" % (n, m))
     assert res["losses"][-1] < res["losses"][0]
+
+
+@pytest.mark.parametrize("world", WORLDS)
+@pytest.mark.parametrize("case", ["sync_momentum", "sync_momentum_a2a", "sync_adam_clip", "sync_momentum_ps1",
+                                  "stale2_momentum"])
+def test_sharded_ps_on_the_native_communicator(tmp_path, case, world):
+    """The same cases on direct RCCL calls (native/rccl_comm.cpp): ncclUniqueId through the TCPStore on rank 0's
+    address, ncclCommInitRank per rank, every push / pull / norm all-reduce one C call on the comm stream."""
+    _need(world)
+    from test_distributed import single_process_reference
+
+    res = run_gpu_ranks(world, case, tmp_path, backend="rccl-native")
+    if case.startswith("stale"):
+        assert abs(res["losses"][0] - res["losses"][2]) < 1e-6 and res["losses"][-1] < res["losses"][0]
+        return
+    ref, _ = single_process_reference("adam" if "adam" in case else "momentum", "clip" in case)
+    for n, p in ref.items():
+        torch.testing.assert_close(res["params"][n], p, rtol=5e-4, atol=5e-5, msg=lambda m: "%s: %s" % (n, m))
 
 
 @pytest.mark.parametrize("world", WORLDS)
