@@ -353,9 +353,10 @@ def restore_ps(ps, export_dir, step=None, tf_names=None):
                     a, b = max(var_off, lo), min(var_off + length, hi)
                     if a < b:
                         dst[shard_off + (a - var_off):shard_off + (b - var_off)].copy_(flat_of(vname)[a - lo:b - lo])
-        # the full variable, for the local wire-dtype copy the model computes with
-        for name, lo, hi, _ in segs:
-            ps.param_flat[slot.flat_off + lo:slot.flat_off + hi].copy_(flat_of(name))
+        # the full variable, for the local wire-dtype copy the model computes with (a dedicated PS task has none)
+        if getattr(ps, "param_flat", None) is not None:
+            for name, lo, hi, _ in segs:
+                ps.param_flat[slot.flat_off + lo:slot.flat_off + hi].copy_(flat_of(name))
     ps.global_step = rd.step
     if getattr(ps, "hyper", None) is not None:
         ps.hyper[2:3].fill_(float(rd.step + 1))

@@ -23,6 +23,13 @@ async  (TF1 default): each worker talks to every PS point-to-point on its own
        communicator stream, and a worker that has not sent yet blocks nobody.
 When every worker has signalled done the PS leaves its loop, optionally writes
 its checkpoint shard, and blocks until it is killed.
+
+Checkpoints: PS task j writes shard j (master + slots), the chief writes the
+replicated state and -- after a barrier -- the index that publishes the checkpoint.  At the
+end of training in both modes; in sync mode also every ``ckpt_every`` steps (the PS and the
+workers are in lockstep there, so "after step s" is the same moment everywhere).  Resume
+(``restore``): the PS tasks load master + slots of THEIR shard from a checkpoint written by
+any placement / task count, the workers load the variables they compute with.
 """
 from __future__ import annotations
 
@@ -77,9 +84,10 @@ class PSServer(_Base):
         self.global_step = 0
         self.lr = self.opt.lr
 
-    def _init_from_chief(self):
+    def _init_from_chief(self, adopt=True):
         """Initial values come from worker 0 (the chief), like TF's chief
-        running the init op against the PS-hosted variables."""
+        running the init op against the PS-hosted variables.  ``adopt=False`` (resumed job): the broadcasts still
+        run -- the workers are in them -- but the restored master is kept."""
         L = self.layout
         chief = self.P
         for bk in L.buckets:
@@ -87,20 +95,36 @@ class PSServer(_Base):
                 n = bk.shard
                 buf = torch.zeros(n, dtype=self.wire_dtype, device=self.device)
                 self.comm.broadcast(buf, chief)
-                if j == self.j:
+                if j == self.j and adopt:
                     self.master[bk.shard_off:bk.shard_off + n].copy_(buf)
 
-    def serve(self):
-        self._init_from_chief()
+    # what checkpoint.restore_ps needs of a "ps" object: this task hosts shard j of P and computes with nothing
+    param_flat = None
+    hosted = True
+
+    def restore(self, export_dir, named_meta_params, tf_names):
+        """Resume: load master + optimizer slots of shard j (re-partitioned from whatever wrote the checkpoint)."""
+        from . import checkpoint as ckpt
+
+        self.params = [p for _, p in named_meta_params]
+        rd = ckpt.restore_ps(self, export_dir, tf_names=tf_names)
+        self.global_step = rd.step
+        return rd
+
+    def serve(self, ckpt_every=0, write_shard=None, skip_init=False):
+        """``ckpt_every`` / ``write_shard(step)``: sync mode writes shard j every that many steps and then meets the
+        workers in a barrier (the chief publishes the index after it)."""
+        self._init_from_chief(adopt=not skip_init)
         if self.update_mode == "async":
             self._serve_async()
         else:
-            self._serve_sync()
+            self._serve_sync(int(ckpt_every or 0), write_shard)
         return self.global_step
 
-    def _serve_sync(self):
+    def _serve_sync(self, ckpt_every=0, write_shard=None):
         L = self.layout
         ctrl = torch.zeros(2, dtype=torch.float32, device=self.device)
+        first_step = self.global_step
         while True:
             ctrl.zero_()
             self.comm.all_reduce(ctrl)
@@ -119,6 +143,10 @@ class PSServer(_Base):
                     else:
                         self.comm.broadcast(g, j)
             self.global_step += 1
+            if ckpt_every and write_shard is not None and self.global_step % ckpt_every == 0 \
+                    and self.global_step > first_step:
+                write_shard(self.global_step)
+                self.comm.barrier()         # the workers wait here too; the chief then writes the index
 
     def _serve_async(self, poll_s=50e-6):
         """One posted ``irecv`` per worker, served in arrival order.
@@ -302,6 +330,20 @@ class PSWorkerClient(_Base):
 
     def flush(self):
         pass
+
+    # what checkpoint.restore_ps needs: a worker hosts no PS state, it only refreshes what it computes with
+    hosted = False
+    master = slot_m = slot_v = torch.zeros(0)
+
+    def restore(self, export_dir, tf_names):
+        from . import checkpoint as ckpt
+
+        rd = ckpt.restore_ps(self, export_dir, tf_names=tf_names)
+        self._sync_params()
+        return rd
+
+    def _unpack_params(self):
+        self._sync_params()
 
     def set_lr(self, lr):
         # the learning rate lives on the PS in this placement

@@ -129,9 +129,15 @@ class NativeComm(Comm):
             if store is None:
                 import torch.distributed as dist
 
+                # under torchrun the launcher agent already serves a TCPStore on MASTER_PORT
+                # (TORCHELASTIC_USE_AGENT_STORE): every rank is a client then; otherwise rank 0 hosts it
+                agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
                 store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29533")),
-                                      world, rank == 0, timeout=datetime.timedelta(seconds=timeout_s),
+                                      world, (rank == 0) and not agent, timeout=datetime.timedelta(seconds=timeout_s),
                                       wait_for_workers=False)
+                if agent:
+                    key_prefix = "dtf/%s/" % os.environ.get("TORCHELASTIC_RUN_ID", "run")
+                    store = dist.PrefixStore(key_prefix, store)
             key = "dtf/rccl_id/%d" % gen
             if rank == 0:
                 _check(L.dtf_rccl_unique_id(buf), "ncclGetUniqueId")

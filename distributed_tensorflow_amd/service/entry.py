@@ -188,6 +188,9 @@ def _main_staged(t_start, argv, job_name, task_index, ps_csv, worker_csv, file_f
                            "LOCAL_RANK": "0", "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
         import runpy
 
+        from ..utils import miopen as miopen_cache
+
+        miopen_cache.unrestrict()       # the solver restriction is for the framework's own models only
         sys.argv = [spec] + argv
         try:
             runpy.run_path(spec, run_name="__main__")

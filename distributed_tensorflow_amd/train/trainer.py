@@ -259,18 +259,31 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
                                                              srv.update_mode), flush=True)
         from ..parallel.dedicated_ps import agree_on_step
 
-        steps = agree_on_step(comm, srv.serve())
-        print("[ps %d] all workers done after %d applies" % (task_index, steps), flush=True)
-        if do_ckpt:
+        def ps_sections():
             sec = {"": srv.master}
             names = opt.slots
             if names:
                 sec[names[0]] = srv.slot_m
             if len(names) > 1:
                 sec[names[1]] = srv.slot_v
-            ckpt.write_shard(export, steps, task_index, num_ps, sec)
-            print("[ps %d] wrote checkpoint shard" % task_index, flush=True)
-            on_checkpoint(steps, None, False)       # the shard is (remotely) in place before the barrier below
+            return sec
+
+        def write_shard(step):
+            ckpt.write_shard(export, step, task_index, num_ps, ps_sections())
+            on_checkpoint(step, None, False)
+            print("[ps %d] wrote checkpoint shard of step %d" % (task_index, step), flush=True)
+
+        resumed = False
+        if opts.resume and do_ckpt and ckpt.latest_step(export) is not None:
+            tfn = mod.tf_variable_names(meta_model) if hasattr(mod, "tf_variable_names") else {}
+            rd = srv.restore(export, trainable(meta_model.named_parameters()), tfn)
+            resumed = True
+            print("[ps %d] resumed shard from step %d" % (task_index, rd.step), flush=True)
+        steps = agree_on_step(comm, srv.serve(ckpt_every=opts.ckpt_every if do_ckpt else 0, write_shard=write_shard,
+                                              skip_init=resumed))
+        print("[ps %d] all workers done after %d applies" % (task_index, steps), flush=True)
+        if do_ckpt:
+            write_shard(steps)          # the shard is (remotely) in place before the barrier below
         # shards first, index second: the chief publishes the index + 'checkpoint' pointer only after every PS task
         # has passed this barrier, so a reader that follows the pointer always finds the data files
         comm.barrier()
@@ -304,8 +317,19 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
     mark("PS runtime ready")
     tf_names = mod.tf_variable_names(model) if hasattr(mod, "tf_variable_names") else {}
     start_step = 0
-    if opts.resume and do_ckpt and placement != "dedicated" and ckpt.latest_step(export) is not None:
-        start_step = restore_checkpoint(model, ps, export, tf_names)
+    if opts.resume and do_ckpt and ckpt.latest_step(export) is not None:
+        if placement == "dedicated":
+            # the PS tasks restore master + slots of their shards; a worker restores what it computes with and
+            # the replicated state.  Asynchronous checkpoints are labelled in applies (W per worker step).
+            rd = ps.restore(export, tf_names)
+            rep = rd.replicated()
+            with torch.no_grad():
+                for n, b in model.named_buffers():
+                    if n in rep:
+                        b.copy_(rep[n])
+            start_step = rd.step if ps.update_mode == "sync" else rd.step // max(1, num_workers)
+        else:
+            start_step = restore_checkpoint(model, ps, export, tf_names)
         print("[worker %d] resumed from step %d" % (task_index, start_step), flush=True)
     bkw = {k: int(v) for k, v in opts.extra.items() if k in ("seq_len", "image_size")}
     if getattr(mod, "NEEDS_COMM", False):
@@ -324,9 +348,23 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
                 now = time.time()
                 metrics(t_step1=now, first_loss=float(loss.detach().float().item()))
                 print("[worker 0] first step done %.3f s after task start" % (now - t_start), flush=True)
-        if opts.ckpt_every and do_ckpt and step % opts.ckpt_every == 0 and placement != "dedicated":
-            save_checkpoint(model, ps, export, step, tf_names, chief)
-            on_checkpoint(step, comm, chief)
+        if opts.ckpt_every and do_ckpt and step % opts.ckpt_every == 0:
+            if placement != "dedicated":
+                save_checkpoint(model, ps, export, step, tf_names, chief)
+                on_checkpoint(step, comm, chief)
+            elif ps.update_mode == "sync":
+                comm.barrier()          # every PS task has written shard `step` (PSServer._serve_sync)
+                if chief:
+                    publish_dedicated(step)
+
+    def publish_dedicated(step):
+        """The chief's part of a dedicated-placement checkpoint: replicated state, then the index (the pointer)."""
+        shapes = {nm: tuple(p.shape) for nm, p in ps.named_params}
+        orders = {nm: ckpt.storage_order(p) for nm, p in ps.named_params}
+        variables = ckpt.dense_variable_index(ps.layout, tf_names, shapes, opt.slots, orders)
+        ckpt.write_replicated(export, step, replicated_state(model, ps, step))
+        ckpt.write_index(export, step, num_ps, variables, extra={"optimizer": opt.kind, "placement": "dedicated"})
+        on_checkpoint(step, None, True)
 
     remaining = max(0, opts.steps - start_step)
     items = opts.batch * num_workers
@@ -340,13 +378,7 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
         applies = ps.finish()
         comm.barrier()          # every PS task has written its shard (see the ps branch above)
         if do_ckpt and chief:
-            shapes = {nm: tuple(p.shape) for nm, p in ps.named_params}
-            orders = {nm: ckpt.storage_order(p) for nm, p in ps.named_params}
-            variables = ckpt.dense_variable_index(ps.layout, tf_names, shapes, opt.slots, orders)
-            ckpt.write_replicated(export, applies, replicated_state(model, ps, applies))
-            ckpt.write_index(export, applies, num_ps, variables, extra={"optimizer": opt.kind,
-                                                                         "placement": "dedicated"})
-            on_checkpoint(applies, None, True)
+            publish_dedicated(applies)
     else:
         if one_sided:
             ps.finish()         # every worker's last apply has landed

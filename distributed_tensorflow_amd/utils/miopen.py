@@ -35,9 +35,25 @@ def restrict_solvers():
     exported wins; ``DTF_MIOPEN_ALL_SOLVERS=1`` leaves MIOpen's defaults alone."""
     if os.environ.get("DTF_MIOPEN_ALL_SOLVERS", "0") == "1":
         return False
+    mine = []
     for k in _NON_IGEMM:
-        os.environ.setdefault(k, "0")
+        if k not in os.environ:
+            os.environ[k] = "0"
+            mine.append(k)
+    if mine:
+        # remembered so that unrestrict() removes exactly what this function added, never a value the user exported
+        os.environ["DTF_MIOPEN_RESTRICTED"] = ",".join(
+            sorted(set(mine) | set(filter(None, os.environ.get("DTF_MIOPEN_RESTRICTED", "").split(",")))))
     return True
+
+
+def unrestrict():
+    """Undo :func:`restrict_solvers` for code that is not this framework's: a user ``file=`` script gets MIOpen with
+    its own defaults (grouped / depthwise / 3-D / odd fp32 shapes may have no implicit-GEMM solver at all), whether
+    the process is a cold start or a warm rank that had called :func:`setup` while idle.  Effective as
+    long as MIOpen has not created a handle yet, which is the case in both."""
+    for k in filter(None, os.environ.pop("DTF_MIOPEN_RESTRICTED", "").split(",")):
+        os.environ.pop(k, None)
 
 
 def setup(force=False):

@@ -377,3 +377,19 @@ def test_gpu_hot_pool_hands_the_device_its_own_rank_and_respawns(tmp_path):
         ApiConfig.override("launcher", "warm_gpu_pool", "0")
         ApiConfig.override("launcher", "verify_reclaim", "1")
         ApiConfig.override("image", "tensorflow", "tests.fake_task")
+
+
+def test_miopen_solver_restriction_is_undone_for_user_scripts(monkeypatch):
+    """``restrict_solvers`` sets MIOPEN_DEBUG_CONV_{DIRECT,WINOGRAD,FFT,GEMM}=0 process-wide; a user
+    ``file=`` script must not inherit that (it used to, but only on warm starts).  ``unrestrict`` removes exactly the
+    variables the framework added and keeps a value the user exported."""
+    from distributed_tensorflow_amd.utils import miopen
+
+    for k in miopen._NON_IGEMM + ("DTF_MIOPEN_RESTRICTED", "DTF_MIOPEN_ALL_SOLVERS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MIOPEN_DEBUG_CONV_FFT", "1")            # the user's own choice
+    assert miopen.restrict_solvers()
+    assert os.environ["MIOPEN_DEBUG_CONV_DIRECT"] == "0" and os.environ["MIOPEN_DEBUG_CONV_FFT"] == "1"
+    miopen.unrestrict()
+    assert "MIOPEN_DEBUG_CONV_DIRECT" not in os.environ and "MIOPEN_DEBUG_CONV_WINOGRAD" not in os.environ
+    assert os.environ["MIOPEN_DEBUG_CONV_FFT"] == "1" and "DTF_MIOPEN_RESTRICTED" not in os.environ

@@ -288,3 +288,53 @@ def test_untuned_shape_reaches_first_step_quickly(tmp_path):
     assert float(m.group(1)) < 15.0, "first step of an untuned shape took %s s" % m.group(1)
     rec = json.loads(p.stdout.strip().splitlines()[-1])
     assert rec["config"]["miopen_shipped_db"] is True and rec["value"] > 0
+
+
+def test_convolutions_without_an_implicit_gemm_solver_still_run_under_the_restricted_solver_set(tmp_path):
+    """``utils/miopen.restrict_solvers`` leaves only MIOpen's implicit-GEMM family enabled.  Shapes that
+    family may not cover -- depthwise / grouped, fp32 with odd sizes, 3-D -- must still compute the right thing (in a
+    fresh process, with the restriction in the environment before MIOpen loads).  Reference: the same convolution with
+    MIOpen switched off (PyTorch's native kernels)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+from distributed_tensorflow_amd.utils import miopen
+miopen.setup()
+assert os.environ.get("MIOPEN_DEBUG_CONV_DIRECT") == "0"
+import torch, torch.nn.functional as F
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+cases = [
+    ("depthwise bf16", dict(x=(8, 64, 28, 28), w=(64, 1, 3, 3), groups=64, dtype=torch.bfloat16, pad=1)),
+    ("grouped bf16", dict(x=(4, 96, 17, 17), w=(192, 24, 3, 3), groups=4, dtype=torch.bfloat16, pad=1)),
+    ("fp32 odd", dict(x=(3, 5, 13, 11), w=(7, 5, 3, 2), groups=1, dtype=torch.float32, pad=0)),
+    ("3-D fp32", dict(x=(2, 4, 6, 9, 9), w=(6, 4, 3, 3, 3), groups=1, dtype=torch.float32, pad=1)),
+]
+for name, c in cases:
+    x = torch.randn(*c["x"], device=dev).to(c["dtype"]).requires_grad_()
+    w = torch.randn(*c["w"], device=dev).to(c["dtype"]).mul_(0.1).requires_grad_()
+    conv = F.conv3d if len(c["x"]) == 5 else F.conv2d
+    y = conv(x, w, padding=c["pad"], groups=c["groups"])
+    y.float().square().mean().backward()
+    gx, gw = x.grad.clone(), w.grad.clone()
+    x.grad = w.grad = None
+    with torch.backends.cudnn.flags(enabled=False):
+        yr = conv(x, w, padding=c["pad"], groups=c["groups"])
+        yr.float().square().mean().backward()
+    tol = 5e-2 if c["dtype"] == torch.bfloat16 else 2e-3
+    for a, b, what in ((y, yr, "y"), (gx, x.grad, "dx"), (gw, w.grad, "dw")):
+        err = (a.float() - b.float()).abs().max().item() / max(1e-6, b.float().abs().max().item())
+        assert err < tol, (name, what, err)
+    print("ok", name)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    for k in ("MIOPEN_DEBUG_CONV_DIRECT", "MIOPEN_DEBUG_CONV_WINOGRAD", "MIOPEN_DEBUG_CONV_FFT", "MIOPEN_DEBUG_CONV_GEMM",
+              "MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR", "DTF_MIOPEN_ALL_SOLVERS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok ") == 4, r.stdout
