@@ -218,14 +218,19 @@ def main():
                 # which is faster HERE?  A replay costs the host one call instead of ~550 launches, but the step is
                 # GPU-bound on one MI355X and the graph's per-node dispatch measured 0.5-1.5 % SLOWER than a full
                 # eager queue (profiles/r3_graph_vs_eager.txt).  Six timed steps each way, untimed for the result.
-                def trial(fn, n=6):
+                def trial(fn, n=8):
+                    # device-side time of n steps AFTER the queue has filled (two untimed steps first): the host
+                    # enqueues an eager step in ~13 ms against ~20 ms of GPU work, so wall time over a few steps
+                    # from an empty queue would charge the eager loop its ramp-up
                     fn()
-                    torch.cuda.synchronize()
-                    t_ = time.perf_counter()
+                    fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     for _ in range(n):
                         fn()
+                    e1.record()
                     torch.cuda.synchronize()
-                    return (time.perf_counter() - t_) / n
+                    return e0.elapsed_time(e1) / n / 1e3
 
                 te, tg = trial(eager_step), trial(graph_step)
                 graph_trial = {"eager_ms": round(te * 1e3, 3), "graph_ms": round(tg * 1e3, 3)}
