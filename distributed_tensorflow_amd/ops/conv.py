@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import streams as _streams
+
 _MM_BWD_DATA_MIN_CIN = int(os.environ.get("DTF_CONV1X1_MM_DGRAD_MIN_CIN", "128"))
 _MM_FWD_MIN_CIN = int(os.environ.get("DTF_CONV1X1_MM_FWD_MIN_CIN", "1024"))
 _MM_FWD_SKIP = {int(c) for c in os.environ.get("DTF_CONV1X1_MM_FWD_SKIP", "").split(",") if c}
@@ -84,10 +86,67 @@ _ENABLED = os.environ.get("DTF_CONV1X1_MM", "1") != "0"      # A/B switch: 0 = e
 _FORK = os.environ.get("DTF_CONV1X1_FORK", "1") != "0"        # A/B switch: 0 = autograd sums the shortcut grad
 
 
+# K19 (csrc/conv1x1_wrw_kernels.hip): streaming weight gradient of the 64 <-> 256-channel 1x1 layers of the 56 x 56 stage
+# (MIOpen: CK batched GEMM + workspace fill, 106-157 us per call at batch 256; K19: see profiles/r3_k19_wrw1x1.txt)
+_WRW_STREAM = os.environ.get("DTF_CONV1X1_WRW_STREAM", "1") != "0"
+_WRW_STREAM_MIN_ROWS = int(os.environ.get("DTF_CONV1X1_WRW_STREAM_MIN_ROWS", "131072"))
+_wrw_stream_declared = False
+_wrw_stream_ws = {}
+
+
+def wrw_stream_ok(dy2, x2):
+    """``dy2`` [M, Cout], ``x2`` [M, Cin] bf16 rows: can K19 take ``dW = dy2^T . x2``?"""
+    if not (_WRW_STREAM and _ENABLED and dy2.is_cuda and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+            and dy2.dim() == 2 and x2.dim() == 2 and dy2.shape[0] == x2.shape[0]
+            and (dy2.shape[1], x2.shape[1]) in ((256, 64), (64, 256))
+            and dy2.shape[0] % 64 == 0 and dy2.shape[0] >= _WRW_STREAM_MIN_ROWS
+            and dy2.is_contiguous() and x2.is_contiguous() and dy2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
+        return False
+    from . import hip
+
+    return hasattr(hip.lib(), "dtf_wrw1x1")
+
+
+def wrw_stream(dy2, x2):
+    """``dy2 [M, Cout]^T . x2 [M, Cin] -> [Cout, Cin]`` (bf16, fp32 accumulation, fixed summation order) on K19."""
+    global _wrw_stream_declared
+    import ctypes
+
+    from . import hip
+
+    lib = hip.lib()
+    if not _wrw_stream_declared:
+        P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        hip.declare("dtf_wrw1x1_ok", [L], I)
+        hip.declare("dtf_wrw1x1_workspace_floats", [L], L)
+        hip.declare("dtf_wrw1x1", [P, P, P, P, L, I, P])
+        _wrw_stream_declared = True
+    M, cout = dy2.shape
+    cin = x2.shape[1]
+    dev = dy2.device
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _wrw_stream_ws.get(key)
+    if ws is None:
+        ws = _wrw_stream_ws[key] = torch.empty(int(lib.dtf_wrw1x1_workspace_floats(M)), dtype=torch.float32, device=dev)
+    out = torch.empty(cout, cin, dtype=torch.bfloat16, device=dev)
+    if cout == 256:         # A = dY (256 channels), B = X: C = dW
+        rc = lib.dtf_wrw1x1(hip.ptr(dy2), hip.ptr(x2), hip.ptr(out), hip.ptr(ws), M, 0, hip.stream())
+    else:                   # A = X (256 channels), B = dY: C = dW^T, stored transposed
+        rc = lib.dtf_wrw1x1(hip.ptr(x2), hip.ptr(dy2), hip.ptr(out), hip.ptr(ws), M, 1, hip.stream())
+    hip.check(rc, "dtf_wrw1x1")
+    return out
+
+
 def _wrw(dy, x, weight):
     """dW of a 1x1 stride-1 convolution: K6T (``dY^T . X`` with the pixels as reduction rows, no zero-fill /
-    cast passes around it) for wide layers, MIOpen otherwise."""
+    cast passes around it) for wide layers, K19 for the 64 <-> 256-channel layers of the 56 x 56 stage, MIOpen
+    otherwise."""
     cout, cin = weight.shape[0], weight.shape[1]
+    if weight.dtype == torch.bfloat16 and (cout, cin) in ((256, 64), (64, 256)) \
+            and dy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last):
+        dy2, x2 = _rows(dy), _rows(x)
+        if wrw_stream_ok(dy2, x2):
+            return _as_filter1x1(wrw_stream(dy2, x2))
     # measured (scripts/wrw1x1_bench.py): K6T wins from 128 channels on both sides up to ~2.6e5 pixels (ResNet's 28x28
     # and Inception's 17x17 / 8x8 stages), from 192 channels beyond; the 56x56 layers are HBM-bound and MIOpen's
     if _TN_WRW and (min(cin, cout) >= _TN_WRW_MIN_C
@@ -214,7 +273,7 @@ class _Conv1x1Fn(torch.autograd.Function):
             dx, _, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
                                                            [0, 0], 1, [True, False, False])
         if need_dw:
-            dw = _wrw(dy, x, weight)
+            dw = _streams.run_wgrad(lambda: _wrw(dy, x, weight), weight, dy, x)
         return dx, dw, None
 
 
@@ -386,7 +445,7 @@ class _Conv1x1ForkFn(torch.autograd.Function):
                 dx2 = _rows(dskip).addmm_(_rows(dy), w2) if ctx.own else torch.addmm(_rows(dskip), _rows(dy), w2)
             dx = dx2.view(N, H, W, cin).permute(0, 3, 1, 2)
         if need_dw:
-            dw = _wrw(dy, x, weight)
+            dw = _streams.run_wgrad(lambda: _wrw(dy, x, weight), weight, dy, x)
         return dx, dw, None
 
 
@@ -799,14 +858,24 @@ class _ConvFn(torch.autograd.Function):
                   and conv_wrw_eligible(dy, x, weight, stride, padding))
         use_fwd = ctx.needs_input_grad[0] and _dgrad_as_fwd_ok(x, weight, stride, padding)
         mask = [ctx.needs_input_grad[0] and not use_fwd, ctx.needs_input_grad[1] and not use_tn, False]
-        if mask[0] or mask[1]:
-            gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, list(stride), list(padding), [1, 1], False,
-                                                            [0, 0], 1, mask)
-            dx, dw = (gx if mask[0] else None), (gw if mask[1] else None)
+        if mask[0] and mask[1] and _streams.ENABLED:
+            # the library's data gradient on this stream, its weight gradient on the side stream
+            dx, _, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, list(stride), list(padding), [1, 1], False,
+                                                           [0, 0], 1, [True, False, False])
+            dw = _streams.run_wgrad(lambda: torch.ops.aten.convolution_backward(
+                dy, x, weight, None, list(stride), list(padding), [1, 1], False, [0, 0], 1, [False, True, False])[1], weight, dy, x)
+        elif mask[0] or mask[1]:
+            if mask[1] and not mask[0]:
+                dw = _streams.run_wgrad(lambda: torch.ops.aten.convolution_backward(
+                    dy, x, weight, None, list(stride), list(padding), [1, 1], False, [0, 0], 1, [False, True, False])[1], weight, dy, x)
+            else:
+                gx, gw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, list(stride), list(padding), [1, 1],
+                                                                False, [0, 0], 1, mask)
+                dx, dw = (gx if mask[0] else None), (gw if mask[1] else None)
         if use_fwd:
             dx = dgrad_as_forward(dy, weight, padding)
         if use_tn:
-            dw = conv_wrw(dy, x, weight, stride, padding)
+            dw = _streams.run_wgrad(lambda: conv_wrw(dy, x, weight, stride, padding), weight, dy, x)
         return dx, dw, None, None, None
 
 

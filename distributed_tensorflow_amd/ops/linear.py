@@ -223,13 +223,20 @@ class _FusedLinear(torch.autograd.Function):
                 else:
                     dx = torch.addmm(ds2, dz, weight).view(ctx.shape)
         dw = None
+        # the weight gradient is off the critical path: on the side stream (ops/streams.py) it shares the chip with the
+        # next node's LayerNorm / attention / activation backward instead of running in series with them
+        from . import streams as _streams
+
+        # ... unless dZ IS the residual gradient this node returns (no activation + residual): the node that receives it
+        # may accumulate onto it in place (own_skip_grad) while the side stream still reads it
+        side = _streams.run_wgrad if not (ctx.has_res and dz.data_ptr() == dy.data_ptr()) else (lambda fn, *t: (_streams.join_into(torch.cuda.current_stream(dy.device), dy.device), fn())[1])
         if fuse_dbias:
-            dw, dbias = gemm_tn(dz, x2, colsum_dtype=ctx.bias_dtype)
+            dw, dbias = side(lambda: gemm_tn(dz, x2, colsum_dtype=ctx.bias_dtype), weight, dz, x2)
         elif ctx.needs_input_grad[1]:
             if gemm_tn_eligible(dz, x2) and weight.dtype == torch.bfloat16:
-                dw = gemm_tn(dz, x2)                    # K6T: transposed-operand MFMA GEMM, split over M
+                dw = side(lambda: gemm_tn(dz, x2), weight, dz, x2)          # K6T: transposed-operand MFMA GEMM, split over M
             else:
-                dw = torch.matmul(dz.t(), x2)
+                dw = side(lambda: torch.matmul(dz.t(), x2), weight, dz, x2)
         return dx, dw, dbias, dres, None, None, None, None
 
 

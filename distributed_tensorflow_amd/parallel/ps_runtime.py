@@ -55,6 +55,7 @@ import torch
 from ..ops import bucket as bucket_ops
 from ..ops import optim as optim_ops
 from ..ops import reduce as reduce_ops
+from ..ops import streams as streams_mod
 from .comm import Comm
 from .layout import FlatLayout
 
@@ -320,6 +321,7 @@ class ShardedPS:
             yield
             return
         self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+        streams_mod.join_into(self.comm_stream, self.device)        # weight gradients computed on their side stream
         with torch.cuda.stream(self.comm_stream):
             yield
 
@@ -442,6 +444,10 @@ class ShardedPS:
     def step(self):
         """Finish the update of the step whose backward just ran."""
         nb = len(self.layout.buckets)
+        if self.is_cuda:
+            # the compute stream rejoins the weight-gradient side stream (ops/streams.py): everything that follows on
+            # it -- packs of a stale step, the next forward, the end of a hipGraph capture -- is ordered after it
+            streams_mod.join_into(torch.cuda.current_stream(self.device), self.device)
         if self.update_mode == "stale":
             self._step_stale()
         elif self.gnorm_sq is not None:

@@ -351,3 +351,31 @@ def test_conv1x1_n64_module_paths(dev):
         c2.backward(g.float())
         assert float((x.grad.float() - x2.grad).norm() / x2.grad.norm()) < 5e-3
         assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 2e-2
+
+
+@pytest.mark.parametrize("cout,cin", [(256, 64), (64, 256)])
+@pytest.mark.parametrize("N,H", [(64, 56), (24, 56), (8, 128)])
+def test_k19_streaming_1x1_weight_gradient_matches_fp32(dev, cout, cin, N, H):
+    """K19 (``conv1x1_wrw_kernels.hip``): dW of the 64 <-> 256-channel 1x1 layers as a pixel-streaming kernel
+    (LDS-DMA tiles, transposing LDS reads, per-block fp32 slabs added in a fixed order).  vs the fp32 product of the
+    same bf16 operands; bitwise repeatable; pixel counts that leave some of the 256 blocks without a tile."""
+    from distributed_tensorflow_amd.ops import conv
+
+    torch.manual_seed(N + cout)
+    x = torch.randn(N, cin, H, H, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = (torch.randn(N, cout, H, H, device=dev, dtype=torch.bfloat16) * 0.1).contiguous(memory_format=torch.channels_last)
+    dy2, x2 = conv._rows(dy), conv._rows(x)
+    if not conv.wrw_stream_ok(dy2, x2):
+        pytest.skip("shape not eligible for K19")
+    got = conv.wrw_stream(dy2, x2)
+    assert got.shape == (cout, cin) and got.dtype == torch.bfloat16
+    ref = torch.zeros(cout, cin, device=dev, dtype=torch.float32)
+    for lo in range(0, dy2.shape[0], 1 << 16):
+        ref += dy2[lo:lo + (1 << 16)].float().t() @ x2[lo:lo + (1 << 16)].float()
+    err = (got.float() - ref).abs().max().item()
+    assert err <= 1e-2 * ref.abs().max().item() + 1e-3, err
+    assert torch.equal(got, conv.wrw_stream(dy2, x2))
+    # through the module path: the 1x1 convolution's autograd node routes its weight gradient here
+    w = (torch.randn(cout, cin, 1, 1, device=dev, dtype=torch.bfloat16) * 0.05).contiguous(memory_format=torch.channels_last)
+    dw = conv._wrw(dy, x, w)
+    assert torch.equal(dw.reshape(cout, cin), got)
