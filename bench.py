@@ -52,12 +52,13 @@ def main():
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--miopen-find", type=int, default=int(os.environ.get("DTF_MIOPEN_FIND", "0")),
                     help="1: let MIOpen benchmark each conv during warm-up (cudnn.benchmark)")
-    ap.add_argument("--graph", type=int, default=int(os.environ.get("DTF_BENCH_GRAPH", "-1")),
-                    help="1: capture the whole step (forward, backward, hook-launched PS pipeline incl. its RCCL "
-                         "collectives) in one hipGraph and replay it, any N, with automatic fallback to eager when the "
-                         "capture fails on any rank; 0: eager; -1 (default): 1 on one GPU (validated bitwise equal to "
-                         "eager there) IF a short timed trial in the warm-up phase finds the replay faster than the eager "
-                         "loop, 0 on several")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("DTF_BENCH_GRAPH", "0")),
+                    help="0 (default): eager -- the step is GPU-bound and a replayed hipGraph runs its nodes without the "
+                         "compute / weight-gradient / comm stream overlap the eager queue gets (measured 20.6 vs 19.9 "
+                         "ms per step on one MI355X); 1: capture the whole step (forward, backward, hook-launched PS "
+                         "pipeline incl. its RCCL collectives) in one hipGraph and replay it, any N, with automatic "
+                         "fallback to eager when the capture fails on any rank (host time 2 ms instead of 15 ms per "
+                         "step); -1: capture on one GPU, then keep whichever a short timed trial finds faster")
     ap.add_argument("--lr-warmup-steps", type=int, default=100,
                     help="gradual warm-up (Goyal et al.): lr = peak * min(1, step / N); 0: constant peak lr")
     ap.add_argument("--profile-dir", default="")
