@@ -245,6 +245,22 @@ def test_resnet50_layer_shapes_at_bench_batch_match_fp32(dev):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+def test_inception_v3_layer_shapes_at_bench_batch_match_fp32(dev):
+    """the same validation for every convolution module geometry Inception-v3 meets at batch 256
+    (recorded from one forward pass of the model: 1x7 / 7x1 / 3x3 / 5x5 / fused-head 1x1 layers on K13, K14, K6T, tuned
+    MIOpen and the recorded GEMM solutions, weight gradients on the side stream): forward, data gradient, weight
+    gradient vs fp32 on NaN-poisoned memory."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "validate_convs.py"), "256", "inception_v3"],
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-1000:]
+    assert "0 of" in r.stdout.splitlines()[-1]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # K17: streaming 1x1 convolution (64 -> 256 channels) with the statistics epilogue (ops/csrc/conv1x1_stats_kernels.hip)
 # ---------------------------------------------------------------------------------------------------------------------
