@@ -36,7 +36,7 @@ def _lib():
             hip.declare("dtf_bn2_fwd_train_pre",
                         [P, P, P, P, P, P, P, P, I, P, P, P, P, Fl, Fl, Fl, Fl, P, P, P, L, I, P, I, P, I, P])
         hip.declare("dtf_bn_fwd_apply", [P, P, P, P, P, P, L, I, I, P])
-        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, L, L, P])
+        hip.declare("dtf_bn_bwd_train", [P, P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, L, L, L, P, P])
         _declared = True
     return lib
 
@@ -52,6 +52,20 @@ def _partial(device, M, C):
         ws = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=device)
         _partial_ws[key] = ws
     return ws
+
+
+_ticket_ws = {}
+
+
+def _tickets(device):
+    """Zeroed ticket counters of the calling stream for the backward reduce kernels' fused finalize (``BnFin`` in
+    csrc/bn_kernels.hip): the kernels leave them zero again, kernels of one stream run in order, and a second stream
+    gets counters of its own."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = _ticket_ws.get(key)
+    if t is None:
+        t = _ticket_ws[key] = torch.zeros(64, dtype=torch.int32, device=device)
+    return t
 
 
 def _nhwc_rows(x):
@@ -181,7 +195,7 @@ class _FusedBNAct(torch.autograd.Function):
             hip.ptr(dy), hip.ptr(x), hip.ptr(mask), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
             stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), hip.ptr(dres),
             dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
-            int(ctx.relu_mode), 0, ctx.ldx, lddx, hip.stream())
+            int(ctx.relu_mode), 0, ctx.ldx, lddx, hip.ptr(_tickets(dev)), hip.stream())
         hip.check(rc, "dtf_bn_bwd_train")
         return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None
 
@@ -331,7 +345,7 @@ class _BNConcat(torch.autograd.Function):
                 dout.data_ptr() + off * 2, hip.ptr(x), None, hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
                 stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), None,
                 dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
-                1 if ctx.relu else 0, Ct, _row_stride(x), lddx, hip.stream())
+                1 if ctx.relu else 0, Ct, _row_stride(x), lddx, hip.ptr(_tickets(dev)), hip.stream())
             hip.check(rc, "dtf_bn_bwd_train (concat)")
             grads += [dx, dgb[0], dgb[1], None, None, None, None]
             off += C

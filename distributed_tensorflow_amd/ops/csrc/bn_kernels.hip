@@ -112,6 +112,20 @@ __device__ __forceinline__ void pool_gather_dy(const PoolGeom& g, int64_t row, i
     for (int k = 0; k < 8; ++k) d[k] = bf16_to_f32(f32_to_bf16(acc[k]));
 }
 
+// Backward finalize folded into the reduction (round 3).  The stand-alone finalize kernel sits on the critical path
+// between the reduce and the apply pass of every layer, and once the weight gradients run on their side stream its few
+// small blocks share the chip with a GEMM: 5 us alone, 11-17 us measured in the step, 53 times.  Here the blocks of one
+// channel tile (blockIdx.y) take a ticket after their partial row is visible device-wide; the block that draws the last
+// ticket folds the tile's gridDim.x rows in a fixed order (so the result does not depend on WHICH block is last --
+// bitwise reproducible) and writes dgamma, dbeta and the apply coefficients for its 64 channels.  The tickets reset
+// themselves, so the counters stay zero between launches (and across hipGraph replays).
+struct BnFin {
+    unsigned* cnt;            // [channel tiles] tickets, zero on entry; null = no fused finalize
+    const void* gamma; const float* invstd;
+    void* dgamma; void* dbeta; float* coef;
+    float inv_count; int pdt;
+};
+
 // partial[(blockIdx.x * 2 + stat) * C + c]
 // U = rows in flight per lane: the single-operand statistics pass needs 8 (64 B per lane is too
 // little to cover the HBM latency: 3.3 TB/s measured), the two-operand backward pass 4.
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
                                                         const float* __restrict__ shift,
                                                         float* __restrict__ partial, int64_t M, int C,
                                                         int rows_per_block, int64_t lddy, int64_t ldx,
-                                                        PoolGeom pg = PoolGeom{}) {
+                                                        PoolGeom pg = PoolGeom{}, BnFin fin = BnFin{}) {
     const int tx = threadIdx.x & 7;
     const int ty = threadIdx.x >> 3;
     const int c0 = blockIdx.y * BN_CT + tx * 8;
@@ -213,7 +227,69 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const unsigned short* __
         const int c = blockIdx.y * BN_CT + cc;
         if (c < C) {
             float s = red[0][stat][cc] + red[1][stat][cc] + red[2][stat][cc] + red[3][stat][cc];
-            partial[((int64_t)bx * 2 + stat) * C + c] = s;
+            float* dst = partial + ((int64_t)bx * 2 + stat) * C + c;
+            // fused finalize: write-through (sc1) stores, so the hand-off needs no L2 write-back in 768 blocks (a
+            // __threadfence() per block measured +4 ms on the ResNet-50 step: every fence walks the L2's dirty lines,
+            // the previous kernel's output included)
+            if (MODE != BN_FWD_STATS && fin.cnt) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = s;
+        }
+    }
+    if (MODE == BN_FWD_STATS || fin.cnt == nullptr) return;
+    // ---- fused finalize: the last block of this channel tile folds the tile's partial rows ----
+    __shared__ int last_s;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its rows have left the CU ...
+    __syncthreads();                                   // ... before the one lane that signals for all of them adds
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(fin.cnt + blockIdx.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == gridDim.x - 1;
+        last_s = last;
+        if (last) {                                    // ONE agent acquire, in the reducer only
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!last_s) return;
+    const int nblk = (int)gridDim.x;
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;          // 16 channel quads x 16 row lanes
+    const int cb = blockIdx.y * BN_CT + cq * 4;
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+    if (cb < C) {
+        const float* pp = partial + cb;
+#pragma unroll 8
+        for (int j = rl; j < nblk; j += 16) {
+            a1 += *reinterpret_cast<const f32x4*>(pp + ((int64_t)j * 2 + 0) * C);
+            a2 += *reinterpret_cast<const f32x4*>(pp + ((int64_t)j * 2 + 1) * C);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {         // row lanes of one wave: lane bits 4, 5
+        a1[k] += __shfl_xor(a1[k], 16, 64); a2[k] += __shfl_xor(a2[k], 16, 64);
+        a1[k] += __shfl_xor(a1[k], 32, 64); a2[k] += __shfl_xor(a2[k], 32, 64);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[wave][0][lane * 4 + k] = a1[k]; red[wave][1][lane * 4 + k] = a2[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) fin.cnt[blockIdx.y] = 0;                   // next launch starts from zero tickets
+    if (threadIdx.x < BN_CT) {
+        const int cc = threadIdx.x, c = blockIdx.y * BN_CT + cc;
+        if (c < C) {
+            const float t1 = ((red[0][0][cc] + red[1][0][cc]) + red[2][0][cc]) + red[3][0][cc];   // sum dy'
+            const float t2 = ((red[0][1][cc] + red[1][1][cc]) + red[2][1][cc]) + red[3][1][cc];   // sum dy' (x - mean)
+            const float is = fin.invstd[c], mu_c = mean[c];
+            const float g = fin.pdt == DTF_BF16 ? load1<DTF_BF16>(fin.gamma, c) : load1<DTF_F32>(fin.gamma, c);
+            const float dg = t2 * is;
+            if (fin.pdt == DTF_BF16) { store1<DTF_BF16>(fin.dgamma, c, dg); store1<DTF_BF16>(fin.dbeta, c, t1); }
+            else { store1<DTF_F32>(fin.dgamma, c, dg); store1<DTF_F32>(fin.dbeta, c, t1); }
+            const float k1 = g * is;
+            const float k2 = -k1 * is * dg * fin.inv_count;
+            const float k3 = -k1 * t1 * fin.inv_count - k2 * mu_c;
+            fin.coef[c] = k1;
+            fin.coef[C + c] = k2;
+            fin.coef[2 * C + c] = k3;
         }
     }
 }
@@ -1053,6 +1129,18 @@ static int launch_fwd_stats(const unsigned short* x, float* partial, int64_t M, 
     return nb;
 }
 
+// DTF_BN_FUSED_FINALIZE: 1 the backward reduce kernels finalize their own channel tile (BnFin), 0 (default) the
+// stand-alone finalize kernel.  Measured through the ResNet-50 step (scripts/gpu_r3_m.sh, A/B/A/B on one box):
+// fused 20.32 / 20.33 ms, stand-alone 20.18 / 20.15 ms -- the reducer's serial fold of rows that the write-through
+// stores dropped from L2 (62-70 GB/s per block, 98-393 KB per tile) plus its acquire cost as much as the launch they
+// replace.  Kept as a switch with its tests; the form with a __threadfence() per block measured 24.5 ms.
+#define BN_MAX_TICKETS 64
+static int bn_fused_on = -1;
+static inline bool bn_fused_finalize(const unsigned* tickets, int ctiles) {
+    if (bn_fused_on < 0) { const char* e = getenv("DTF_BN_FUSED_FINALIZE"); bn_fused_on = e ? (atoi(e) != 0) : 0; }
+    return bn_fused_on && tickets != nullptr && ctiles <= BN_MAX_TICKETS;
+}
+
 static void bn_init_order() {
     if (bn_sweep < 0) {
         const char* e = getenv("DTF_BN_SWEEP");
@@ -1061,6 +1149,9 @@ static void bn_init_order() {
 }
 
 extern "C" {
+
+// run-time form of DTF_BN_FUSED_FINALIZE (tests); returns the previous setting (-1: environment not read yet)
+int dtf_bn_set_fused_finalize(int on) { const int was = bn_fused_on; bn_fused_on = on ? 1 : 0; return was; }
 
 // A/B switch of the row-chunk schedule (see BN_SCHED): 1 sweep, 0 private ranges
 void dtf_bn_set_sweep(int on) { bn_sweep = on ? 1 : 0; }
@@ -1266,7 +1357,8 @@ int dtf_bn_fwd_apply(const void* x, const void* res, void* y, void* mask, const 
 int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void* gamma, int param_dtype,
                      const float* mean, const float* invstd, const float* scale, const float* shift, void* dx,
                      void* dres, void* dgamma, void* dbeta, float* coef, float* partial, int64_t M, int C,
-                     int relu_mode, int64_t lddy, int64_t ldx, int64_t lddx, hipStream_t stream) {
+                     int relu_mode, int64_t lddy, int64_t ldx, int64_t lddx, unsigned* tickets, hipStream_t stream) {
+    // tickets: BN_MAX_TICKETS zeroed uint32 owned by the calling stream (fused finalize, see BnFin), or null
     // lddx: row stride of dx (written into a channel slice of a wider gradient tensor when > C)
     // lddy: row stride (elements) of dy (a channel slice of the concat gradient is read in place)
     DTF_CLEAR_ERRORS();
@@ -1282,6 +1374,8 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
     const unsigned short *dys = (const unsigned short*)dy, *xs = (const unsigned short*)x;
     const unsigned char* ms = (const unsigned char*)mask;
     int nred = nb;
+    bool fused = false;
+    const float inv_count = 1.0f / (float)M;
     // DTF_BN_FLAT_REDUCE: 0 off, 1 flat U=4, 2 flat U=4 non-temporal loads, 3 flat U=2, 4 flat U=2 non-temporal loads
     static int flat_reduce = -1;
     if (flat_reduce < 0) { const char* e = getenv("DTF_BN_FLAT_REDUCE"); flat_reduce = e ? atoi(e) : 0; }
@@ -1297,18 +1391,20 @@ int dtf_bn_bwd_train(const void* dy, const void* x, const void* mask, const void
 #undef FRED_M
 #undef FRED
     } else {
-#define RED(MODE) hipLaunchKernelGGL((bn_reduce_kernel<MODE, BN_UNROLL>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, rpb, lddy, ldx)
+        fused = bn_fused_finalize(tickets, ct);
+        BnFin fin{};
+        if (fused) fin = BnFin{tickets, gamma, invstd, dgamma, dbeta, coef, inv_count, param_dtype};
+#define RED(MODE) hipLaunchKernelGGL((bn_reduce_kernel<MODE, BN_UNROLL>), dim3(nb, ct), dim3(256), 0, stream, xs, dys, ms, mean, scale, shift, partial, M, C, rpb, lddy, ldx, PoolGeom{}, fin)
     if (relu_mode == BN_BWD_RELU_X) RED(BN_BWD_RELU_X);
     else if (relu_mode == BN_BWD_RELU_MASK) RED(BN_BWD_RELU_MASK);
     else RED(BN_BWD_PLAIN);
 #undef RED
     }
-    const float inv_count = 1.0f / (float)M;
     const int fgrid = (C + BN_FIN_CH - 1) / BN_FIN_CH;
-    if (param_dtype == DTF_BF16)
+    if (!fused && param_dtype == DTF_BF16)
         hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_BF16>), dim3(fgrid), dim3(256), 0, stream, partial, nred, C,
                            inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
-    else
+    else if (!fused)
         hipLaunchKernelGGL((bn_bwd_finalize_kernel<DTF_F32>), dim3(fgrid), dim3(256), 0, stream, partial, nred, C,
                            inv_count, gamma, mean, invstd, dgamma, dbeta, coef);
     if (!dx) {          // reduce + finalize only: the consumer applies dx = k1 dy' + k2 x + k3 itself (K15 stem weight gradient)

@@ -144,7 +144,7 @@ class _BNReLUMaxPool(torch.autograd.Function):
         rc = bnmod._lib().dtf_bn_bwd_train(
             hip.ptr(dbn), hip.ptr(x), None, hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(), stats[1].data_ptr(),
             stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), None, dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef),
-            hip.ptr(bnmod._partial(dev, M, C)), M, C, 1, 0, 0, 0, hip.stream())
+            hip.ptr(bnmod._partial(dev, M, C)), M, C, 1, 0, 0, 0, hip.ptr(bnmod._tickets(dev)), hip.stream())
         hip.check(rc, "dtf_bn_bwd_train (pool)")
         return dx, dgb[0], dgb[1], None, None, None, None, None, None, None
 

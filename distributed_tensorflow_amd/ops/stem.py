@@ -151,7 +151,8 @@ class _StemFn(torch.autograd.Function):
             rc = bnmod._lib().dtf_bn_bwd_train(
                 hip.ptr(dbn), hip.ptr(c), None, hip.ptr(gamma), hip.dt(gamma), stats[0].data_ptr(), stats[1].data_ptr(),
                 stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dc), None, dgb[0].data_ptr(),
-                dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(bnmod._partial(dev, M, C)), M, C, 1, 0, 0, 0, hip.stream())
+                dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(bnmod._partial(dev, M, C)), M, C, 1, 0, 0, 0,
+                hip.ptr(bnmod._tickets(dev)), hip.stream())
             hip.check(rc, "dtf_bn_bwd_train (stem)")
         dw = None
         if ctx.needs_input_grad[1]:

@@ -179,6 +179,64 @@ def test_fused_bn_act_matches_pytorch(dev, shape, relu, res, pdt):
         assert d2.float().mean().item() < 2e-3
 
 
+@pytest.mark.parametrize("shape,res", [((64, 64, 56, 56), False), ((32, 256, 28, 28), True), ((16, 2048, 7, 7), True),
+                                       ((8, 72, 17, 17), False)])
+def test_bn_backward_fused_finalize_is_reproducible(dev, shape, res):
+    """The backward reduce kernels finalize their own channel tile (last-ticket block, csrc/bn_kernels.hip BnFin): the
+    result must not depend on which block draws the last ticket, and the tickets must be back at zero after every call
+    -- 40 back-to-back backward passes, alternating with another shape on the same stream, are bitwise identical."""
+    from distributed_tensorflow_amd.ops import hip
+
+    torch.manual_seed(5)
+    N, C, H, W = shape
+    lib = hip.lib()
+    was = lib.dtf_bn_set_fused_finalize(1)
+    try:
+        _fused_finalize_body(dev, shape, res)
+    finally:
+        if was >= 0:
+            lib.dtf_bn_set_fused_finalize(was)
+        else:
+            lib.dtf_bn_set_fused_finalize(0)
+
+
+def _fused_finalize_body(dev, shape, res):
+    N, C, H, W = shape
+
+    def mk(s):
+        return torch.randn(s, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    x, dy = mk(shape), mk(shape)
+    r = mk(shape) if res else None
+    w = (torch.rand(C, device=dev) + 0.5).to(torch.bfloat16)
+    b = torch.zeros(C, device=dev, dtype=torch.bfloat16)
+    other = (mk((4, 128, 9, 9)), mk((4, 128, 9, 9)))
+    w_o = torch.ones(128, device=dev, dtype=torch.bfloat16).requires_grad_()
+
+    def once():
+        x1, w1, b1 = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        r1 = r.clone().requires_grad_() if res else None
+        y = batchnorm.fused_bn_act(x1, w1, b1, r1, None, None, True, 0.1, 1e-5, True)
+        y.backward(dy)
+        return x1.grad, w1.grad, b1.grad
+
+    # numerics against the stand-alone finalize kernel (its own fold order: equal up to fp32 rounding of the sums)
+    lib = __import__("distributed_tensorflow_amd.ops.hip", fromlist=["lib"]).lib()
+    lib.dtf_bn_set_fused_finalize(0)
+    plain = once()
+    lib.dtf_bn_set_fused_finalize(1)
+    first = once()
+    for a, c in zip(plain, first):
+        torch.testing.assert_close(a.float(), c.float(), rtol=2e-2, atol=2e-2 * max(1.0, (N * H * W) ** 0.5 / 8))
+    for _ in range(40):
+        xo = other[0].clone().requires_grad_()
+        batchnorm.fused_bn_act(xo, w_o, torch.zeros_like(w_o), None, None, None, True, 0.1, 1e-5, False).backward(other[1])
+        again = once()
+        for a, c in zip(first, again):
+            assert torch.equal(a, c)
+    assert int(batchnorm._tickets(torch.device(dev)).abs().sum()) == 0
+
+
 def test_fused_bn_eval_mode(dev):
     C = 64
     m = batchnorm.FusedBatchNormAct(C).to(dev).to(torch.bfloat16)
