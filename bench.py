@@ -294,6 +294,7 @@ def main():
                        "wire_dtype": str(ps.wire_dtype).replace("torch.", ""),
                        "update_mode": a.update_mode, "optimizer": opt.kind, "bucket_mb": a.bucket_mb,
                        "comm_backend": str(comm.backend),
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "hipgraph": bool(graph is not None), "hipgraph_trial": graph_trial if a.graph and on_gpu else None, "miopen_find": bool(a.miopen_find), "miopen_shipped_db": bool(miopen_db), "gemm_shipped_db": bool(gemm_db),
                        "baseline": "tf_cnn_benchmarks PS, DGX-1 P100, %s GPU(s): %s img/s" % (n, base),
                        "host_enqueue_ms_per_step": round(t_probe * 1e3, 3),

@@ -393,3 +393,23 @@ def test_miopen_solver_restriction_is_undone_for_user_scripts(monkeypatch):
     miopen.unrestrict()
     assert "MIOPEN_DEBUG_CONV_DIRECT" not in os.environ and "MIOPEN_DEBUG_CONV_WINOGRAD" not in os.environ
     assert os.environ["MIOPEN_DEBUG_CONV_FFT"] == "1" and "DTF_MIOPEN_RESTRICTED" not in os.environ
+
+
+def test_package_import_raises_hw_queue_count(monkeypatch):
+    """A live-communicator rank uses more streams than HIP's default four hardware queues: the package raises
+    GPU_MAX_HW_QUEUES to 8 before the runtime initialises, keeps a larger setting, and DTF_KEEP_HW_QUEUES=1 opts out."""
+    import distributed_tensorflow_amd as pkg
+
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    pkg._ensure_hw_queues()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "16")
+    pkg._ensure_hw_queues()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "16"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    pkg._ensure_hw_queues()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    monkeypatch.setenv("DTF_KEEP_HW_QUEUES", "1")
+    pkg._ensure_hw_queues()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "2"
