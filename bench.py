@@ -76,6 +76,12 @@ def main():
 
         faulthandler.dump_traceback_later(int(os.environ["DTF_BENCH_WATCHDOG"]), exit=True)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import distributed_tensorflow_amd as _pkg
+
+    if a.graph > 0:
+        # the package asked for 8 hardware queues on import (the eager step's streams need them); a replayed graph
+        # wants HIP's default back -- see restore_hw_queues().  --graph -1 (trial) keeps 8: eager is the likely winner
+        _pkg.restore_hw_queues()
     from distributed_tensorflow_amd.utils import miopen as miopen_cache
 
     miopen_db = miopen_cache.setup()      # shipped find-db + kernel cache (offline-tuned convs)

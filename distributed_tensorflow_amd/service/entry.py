@@ -219,6 +219,15 @@ def _main_staged(t_start, argv, job_name, task_index, ps_csv, worker_csv, file_f
                        "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
 
     put = _metrics_sink(uid)
+    if getattr(opts, "graph", False):
+        # a replayed whole-step hipGraph wants HIP's default hardware-queue count back (restore_hw_queues); a GPU-hot
+        # warm rank initialised HIP long ago with the eager setting, where the replay measured 29 vs 21 ms: stay eager
+        from .. import restore_hw_queues
+
+        if not restore_hw_queues():
+            print("[entry] graph=1 ignored on a GPU-hot rank (the HIP runtime is already up with the eager step's "
+                  "hardware-queue count); running eager", flush=True)
+            opts.graph = False
     from ..utils import miopen as miopen_cache
 
     miopen_cache.setup()

@@ -413,3 +413,14 @@ def test_package_import_raises_hw_queue_count(monkeypatch):
     monkeypatch.setenv("DTF_KEEP_HW_QUEUES", "1")
     pkg._ensure_hw_queues()
     assert os.environ["GPU_MAX_HW_QUEUES"] == "2"
+    # a process that will replay a hipGraph puts the caller's setting back (before the HIP runtime starts)
+    monkeypatch.delenv("DTF_KEEP_HW_QUEUES")
+    monkeypatch.setattr(pkg, "_hw_queues_before", pkg._UNSET)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    pkg._ensure_hw_queues()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "8"
+    assert pkg.restore_hw_queues() is True
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "4"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    pkg._ensure_hw_queues()
+    assert pkg.restore_hw_queues() is True and "GPU_MAX_HW_QUEUES" not in os.environ
