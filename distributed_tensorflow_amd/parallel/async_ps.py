@@ -23,11 +23,18 @@ the values its own apply kernels wrote, other workers' updates are picked up at 
 Owners are visited in rotated order (rank r starts with shard r, then r+1, ...), so at any
 moment the W workers tend to target W different owners: every xGMI link carries one stream.
 
+The packs and applies are hook-driven like the synchronous runtime's: when the last gradient
+of a bucket has been accumulated, the bucket is packed and applied to every owner on a second
+stream while backward continues with the earlier layers (``DTF_ASYNC_HOOKS=0``: everything
+after backward, the first version).  With global-norm clipping the applies need the norm of
+the whole gradient, so only the packs move into backward.
+
 The torch.distributed group is used for control only (handle exchange, final barrier): gloo is
 enough, which also makes the mode testable with several processes on ONE GPU.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import tempfile
@@ -39,6 +46,7 @@ from ..ops import bucket as bucket_ops
 from ..ops import hip
 from ..ops import optim as optim_ops
 from ..ops import reduce as reduce_ops
+from ..ops import streams as streams_mod
 from .comm import Comm
 from .layout import FlatLayout
 from .ps_runtime import OptimizerSpec, trainable
@@ -152,7 +160,7 @@ class AsyncPS:
     push = "peer-apply"
 
     def __init__(self, named_params, comm: Comm = None, opt: OptimizerSpec = None, bucket_mb=32.0, wire_dtype=None,
-                 tail_mb=0.0, shm_dir=None):
+                 tail_mb=0.0, shm_dir=None, hooks=None):
         self.comm = comm or Comm.single()
         self.opt = opt or OptimizerSpec()
         self.named_params = trainable(named_params)
@@ -228,6 +236,22 @@ class AsyncPS:
         self._plans = [bucket_ops.PackPlan([L.slots[i].numel for i in bk.params],
                                            [L.slots[i].flat_off for i in bk.params]) for bk in L.buckets]
         self._closed = False
+        # -- hook-driven pipeline (see the module docstring)
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.is_cuda else None
+        nb = len(L.buckets)
+        self._bucket_of = {}
+        for bk in L.buckets:
+            for i in bk.params:
+                self._bucket_of[i] = bk.index
+        self._pending = [len(bk.params) for bk in L.buckets]
+        self._packed = [False] * nb
+        self._applied = [False] * nb
+        self._hooks = []
+        if hooks is None:
+            hooks = os.environ.get("DTF_ASYNC_HOOKS", "1") != "0"
+        if hooks:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_grad(i)))
 
     def _sync_device(self):
         if self.is_cuda:
@@ -248,35 +272,81 @@ class AsyncPS:
             out.append(g)
         return out
 
-    def step(self):
-        """Apply THIS worker's gradients to every owner's shard and pull the result -- no other rank involved."""
+    @contextlib.contextmanager
+    def _on_comm_stream(self):
+        """Run the body on the second stream, ordered after everything launched so far on the current stream and on
+        the weight-gradient side stream (``ops/streams.py``)."""
+        if self.comm_stream is None:
+            yield
+            return
+        self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+        streams_mod.join_into(self.comm_stream, self.device)
+        with torch.cuda.stream(self.comm_stream):
+            yield
+
+    def _on_grad(self, i):
+        b = self._bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._packed[b]:
+            with self._on_comm_stream():
+                self._pack(b)
+                if self.gnorm_sq is None:
+                    self._apply(b)
+
+    def _pack(self, b):
+        self._plans[b].pack(self._grads_of(b), self.grad_flat, 1.0)           # un-averaged: TF1 async semantics
+        self._packed[b] = True
+
+    def _apply(self, b):
+        """This worker's gradient of bucket ``b`` onto every owner's slice of it, owners in rotated order."""
         L, W, r, o = self.layout, self.comm.world_size, self.comm.rank, self.opt
-        for b in range(len(L.buckets)):
-            self._plans[b].pack(self._grads_of(b), self.grad_flat, 1.0)       # un-averaged: TF1 async semantics
-        if self.gnorm_sq is not None:
-            # each worker clips by the norm of ITS OWN gradient (what clip_by_global_norm does in an async graph)
-            reduce_ops.sumsq(self.grad_flat, self.gnorm_sq)
+        bk = L.buckets[b]
+        sl = slice(bk.shard_off, bk.shard_off + bk.shard)
+        wd = o.weight_decay if bk.group == 0 else 0.0
         for k in range(W):
             j = (r + k) % W
-            for bk in L.buckets:
-                lo, hi = L.shard_range(bk.index, j)
-                sl = slice(bk.shard_off, bk.shard_off + bk.shard)
-                wd = o.weight_decay if bk.group == 0 else 0.0
-                common = dict(grad_scale=1.0, hyper=self._hyper[j], gnorm_sq=self.gnorm_sq, max_norm=o.max_grad_norm)
-                if o.kind == "adam":
-                    optim_ops.adam_apply(self.grad_flat[lo:hi], self._master[j][sl], self._m[j][sl], self._v[j][sl],
-                                         self.param_flat[lo:hi], lr=self._lr, beta1=o.beta1, beta2=o.beta2, eps=o.eps,
-                                         wd=wd, adamw=o.adamw, bias_correction=o.bias_correction, step=1, **common)
-                else:
-                    mom = o.momentum if o.kind == "momentum" else 0.0
-                    optim_ops.sgd_momentum_apply(self.grad_flat[lo:hi], self._master[j][sl], self._m[j][sl],
-                                                 self.param_flat[lo:hi], lr=self._lr, momentum=mom, wd=wd,
-                                                 nesterov=o.nesterov, **common)
-            self._hyper[j][2:3].add_(1.0)          # the owner's apply counter (TF global_step); racy by design
+            lo, hi = L.shard_range(bk.index, j)
+            common = dict(grad_scale=1.0, hyper=self._hyper[j], gnorm_sq=self.gnorm_sq, max_norm=o.max_grad_norm)
+            if o.kind == "adam":
+                optim_ops.adam_apply(self.grad_flat[lo:hi], self._master[j][sl], self._m[j][sl], self._v[j][sl],
+                                     self.param_flat[lo:hi], lr=self._lr, beta1=o.beta1, beta2=o.beta2, eps=o.eps,
+                                     wd=wd, adamw=o.adamw, bias_correction=o.bias_correction, step=1, **common)
+            else:
+                mom = o.momentum if o.kind == "momentum" else 0.0
+                optim_ops.sgd_momentum_apply(self.grad_flat[lo:hi], self._master[j][sl], self._m[j][sl],
+                                             self.param_flat[lo:hi], lr=self._lr, momentum=mom, wd=wd,
+                                             nesterov=o.nesterov, **common)
+        self._applied[b] = True
+
+    def step(self):
+        """Apply THIS worker's gradients to every owner's shard and pull the result -- no other rank involved.
+        Buckets whose hooks fired during backward are already packed (and, without clipping, applied) on the second
+        stream; whatever is left happens here, then the calling stream joins."""
+        L, W, r = self.layout, self.comm.world_size, self.comm.rank
+        nb = len(L.buckets)
+        if self.is_cuda:
+            streams_mod.join_into(torch.cuda.current_stream(self.device), self.device)
+        with self._on_comm_stream():
+            for b in range(nb - 1, -1, -1):
+                if not self._packed[b]:
+                    self._pack(b)
+            if self.gnorm_sq is not None:
+                # each worker clips by the norm of ITS OWN gradient (what clip_by_global_norm does in an async graph)
+                reduce_ops.sumsq(self.grad_flat, self.gnorm_sq)
+            for b in range(nb - 1, -1, -1):
+                if not self._applied[b]:
+                    self._apply(b)
+            for k in range(W):
+                self._hyper[(r + k) % W][2:3].add_(1.0)     # the owner's apply counter (TF global_step); racy by design
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         if self._unpack_needed:
             self._unpack_params()
         for p in self.params:
             p.grad = None
+        self._pending = [len(bk.params) for bk in L.buckets]
+        self._packed = [False] * nb
+        self._applied = [False] * nb
         self.global_step += 1
 
     def applies_received(self):
@@ -337,13 +407,16 @@ class AsyncPS:
         return torch.as_strided(flat, p.shape, p.stride(), s.flat_off)
 
     def remove_hooks(self):
-        pass
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def close(self):
         """Detach the model from the shared regions and release them (collective: every rank calls it)."""
         if self._closed:
             return
         self._closed = True
+        self.remove_hooks()
         self._sync_device()
         self.regions._barrier()
         # own-shard views die with the regions: keep private copies for checkpoints written afterwards

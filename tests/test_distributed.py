@@ -153,6 +153,39 @@ def test_one_sided_async_ps_serialised_equals_sequential_sgd(tmp_path, case, wor
         torch.testing.assert_close(res["params"][n], p, rtol=1e-5, atol=1e-6, msg=lambda m: "%s: %s" % (n, m))
 
 
+@pytest.mark.parametrize("kind,clip", [("momentum", 0.0), ("adam", 0.0), ("adam", 0.5)])
+def test_one_sided_async_ps_hook_driven_equals_after_backward(kind, clip):
+    """Packs and applies launched from the gradient hooks during backward (default) == everything after backward
+    (``hooks=False``), bitwise, one worker; with clipping only the packs move into backward."""
+    import copy
+
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncPS
+    from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec
+
+    torch.manual_seed(3)
+    m1 = mnist_mlp.build()
+    m2 = copy.deepcopy(m1)
+    spec = OptimizerSpec(kind=kind, lr=0.01, momentum=0.9, max_grad_norm=clip)
+    a = AsyncPS(list(m1.named_parameters()), opt=spec, bucket_mb=0.05, hooks=True)
+    b = AsyncPS(list(m2.named_parameters()), opt=spec, bucket_mb=0.05, hooks=False)
+    assert len(a.layout.buckets) >= 2 and len(a._hooks) == len(a.params) and not b._hooks
+    for step in range(4):
+        batch = mnist_mlp.synthetic_batch(32, seed=step)
+        for m, ps in ((m1, a), (m2, b)):
+            mnist_mlp.loss_fn(m, batch).backward()
+            if ps is a:      # every bucket was packed by its hook; applied too unless the clip needs the whole norm
+                assert all(a._packed) and all(a._applied) == (clip == 0.0)
+            ps.step()
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q), n
+    assert torch.equal(a.full_master(), b.full_master())
+    assert a.applies_received() == b.applies_received() == 4
+    a.close()
+    b.close()
+    assert not a._hooks
+
+
 def test_one_sided_async_ps_workers_do_not_wait_for_each_other(tmp_path):
     """Free-running: worker 1 sleeps 50 ms per step, worker 0 must not be held back by it (TF1 async semantics: no
     barrier anywhere in the step), the owners count every apply, and training converges."""
