@@ -417,6 +417,10 @@ class LocalCluster:
         self._idle_used = {}
         self._verify = cfg.getboolean("launcher", "verify_reclaim", True) if self._all_gpus else False
         self._sample_wait = cfg.getfloat("launcher", "hbm_sample_wait_seconds", 60.0)
+        # finished Jobs are kept (the reference never deletes worker Jobs: CleanJobHandler only removes the ps side),
+        # which in a long-lived service grows without bound: a finished Job is deleted ``ttlSecondsAfterFinished``
+        # (Job spec, the k8s field) or ``finished_job_ttl_seconds`` (config default for all Jobs) after it ended; 0 = keep
+        self._finished_ttl = cfg.getfloat("launcher", "finished_job_ttl_seconds", 0.0)
         # warm rank pools: only for the framework's own entry module (a custom image starts cold)
         n_warm = cfg.getint("launcher", "warm_pool", 0)
         self._root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -704,6 +708,32 @@ class LocalCluster:
                 self._release_gpus(t)
                 self._schedule()
                 self._respawn_hot(t)
+        self._arm_ttl(t)
+
+    def _arm_ttl(self, t):
+        ttl = (t.body.get("spec") or {}).get("ttlSecondsAfterFinished")
+        try:
+            ttl = float(self._finished_ttl if ttl is None else ttl)
+        except (TypeError, ValueError):
+            ttl = 0.0
+        if ttl <= 0 or t.deleted or self._closed:
+            return
+
+        def expire():
+            with self._lock:
+                gone = self._closed or t.deleted or self._jobs.get((t.namespace, t.name)) is not t
+            if gone:
+                return
+            try:
+                self.delete_namespaced_job(t.name, t.namespace)
+                log.info("finished job %s deleted after its ttl of %.0f s", t.name, ttl)
+            except ApiException:
+                pass
+
+        timer = threading.Timer(ttl, expire)
+        timer.daemon = True
+        timer.name = "job-ttl-" + t.name
+        timer.start()
 
     def _respawn_hot(self, t):
         # caller holds the lock: a released device that nobody took gets a fresh GPU-hot rank

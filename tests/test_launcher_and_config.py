@@ -424,3 +424,29 @@ def test_package_import_raises_hw_queue_count(monkeypatch):
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
     pkg._ensure_hw_queues()
     assert pkg.restore_hw_queues() is True and "GPU_MAX_HW_QUEUES" not in os.environ
+
+
+def test_finished_jobs_are_garbage_collected_after_their_ttl(cluster):
+    """The reference keeps every worker Job forever (only the ps side is reaped); a long-lived service deletes a
+    finished Job ``ttlSecondsAfterFinished`` (Job spec) or ``[launcher] finished_job_ttl_seconds`` after it ended --
+    with a DELETED event like any other deletion -- and keeps Jobs without a ttl, as before."""
+    kept = cluster.create_namespaced_job("default", _job(0, 3, 0, "exit:0"))["metadata"]["name"]
+    body = _job(1, 3, 1, "exit:0")
+    body["spec"]["ttlSecondsAfterFinished"] = 0.3
+    gone = cluster.create_namespaced_job("default", body)["metadata"]["name"]
+    failed = _job(2, 3, 0, "exit:3")
+    failed["spec"]["ttlSecondsAfterFinished"] = 0.3
+    gone2 = cluster.create_namespaced_job("default", failed)["metadata"]["name"]
+
+    def names():
+        return {j["metadata"]["name"] for j in cluster.list_namespaced_job("default")["items"]}
+
+    assert _wait(lambda: cluster.read_namespaced_job(kept, "default")["status"]["succeeded"] == 1)
+    assert _wait(lambda: gone not in names() and gone2 not in names(), timeout=10)
+    assert kept in names() and cluster.free_gpus() == [0, 1]
+    deleted = [e["object"]["metadata"]["name"] for e in cluster.watch("default", 0, timeout=0.2) if e["type"] == "DELETED"]
+    assert sorted(deleted) == sorted([gone, gone2])
+    # the config-wide default applies to Jobs that carry no ttl of their own
+    cluster._finished_ttl = 0.2
+    late = cluster.create_namespaced_job("default", _job(3, 4, 0, "exit:0"))["metadata"]["name"]
+    assert _wait(lambda: late not in names(), timeout=10) and kept in names()
