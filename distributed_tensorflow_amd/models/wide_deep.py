@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..ops import embedding as emb_ops
 from ..ops.linear import fused_linear
 from ..parallel.comm import Comm
 from ..parallel.embedding import ShardedEmbedding
@@ -35,36 +36,13 @@ class _SplitDeepWide(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, e, dense, D, kpad):
-        B, F_, W = e.shape
-        nd = dense.shape[1]
-        ctx.shape, ctx.D, ctx.nd = e.shape, D, nd
-        h = torch.empty(B, F_ * D + nd + kpad, dtype=e.dtype, device=e.device)
-        h[:, :F_ * D].view(B, F_, D).copy_(e[:, :, :D])
-        h[:, F_ * D:F_ * D + nd].copy_(dense)
-        if kpad:
-            h[:, F_ * D + nd:].zero_()
-        wide = e[:, :, D].float().sum(1, keepdim=True)
-        return h, wide
+        ctx.shape, ctx.D, ctx.dtype = e.shape, D, e.dtype
+        # K20 (ops/csrc/rowsplit_kernels.hip) on the GPU: e is read once, h and the wide sums written once
+        return emb_ops.split_rows(e, dense, D, dense.shape[1] + kpad)
 
     @staticmethod
     def backward(ctx, d_h, d_wide):
-        B, F_, W = ctx.shape
-        D = ctx.D
-        dt = d_h.dtype if d_h is not None else d_wide.dtype
-        dev = d_h.device if d_h is not None else d_wide.device
-        # three slice writes into one buffer (a concatenation along the 72-wide last axis runs at a third of the rate)
-        de = torch.empty(B, F_, W, dtype=dt, device=dev)
-        if d_h is not None:
-            de[:, :, :D].copy_(d_h[:, :F_ * D].view(B, F_, D))
-        else:
-            de[:, :, :D].zero_()
-        if d_wide is not None:
-            de[:, :, D:D + 1].copy_(d_wide.to(dt).unsqueeze(1).expand(B, F_, 1))
-        else:
-            de[:, :, D:D + 1].zero_()
-        if W - D - 1 > 0:
-            de[:, :, D + 1:].zero_()
-        return de, None, None, None
+        return emb_ops.merge_rows(d_h, d_wide, ctx.shape, ctx.D, ctx.dtype), None, None, None
 
 
 class WideDeep(nn.Module):

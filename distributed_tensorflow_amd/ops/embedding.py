@@ -32,6 +32,9 @@ def _lib():
         hip.declare("dtf_embedding_segment_plan", [P, L, I, P, P, P, P, P, P])
         hip.declare("dtf_embedding_route", [P, L, I, I, L, L, L, P, P, P, P, P, P, P])
         hip.declare("dtf_route_tile", [])
+        hip.declare("dtf_emb_split_ok", [L, I, I, I, I, I, L])
+        hip.declare("dtf_emb_split_fwd", [P, P, P, P, L, I, I, I, I, L, P])
+        hip.declare("dtf_emb_split_bwd", [P, P, P, L, I, I, L, P])
         _declared = True
     return lib
 
@@ -282,3 +285,81 @@ def dense_embedding(ids, weight):
             and weight.requires_grad and torch.is_grad_enabled() and weight.shape[1] % 8 == 0):
         return _DenseEmbedding.apply(weight, ids)
     return torch.nn.functional.embedding(ids, weight)
+
+
+# ---------------------------------------------------------------------------
+# K20: fused rows [B, F, D + 8] <-> deep-tower input [B, F*D + tail] + summed wide weights [B]
+# ---------------------------------------------------------------------------
+_SPLIT = os.environ.get("DTF_EMB_SPLIT_KERNEL", "1") != "0"      # A/B switch: 0 = tensor expressions
+
+
+def split_rows_reference(e, dense, D, tail):
+    """``e [B, F, D + pad]``, ``dense [B, nd]`` -> ``(h [B, F*D + tail], wide [B, 1] fp32)``: the deep vectors side by
+    side, then the dense features and zeros up to ``tail`` columns; the wide weights (column ``D``) summed over F."""
+    B, F_, W = e.shape
+    nd = dense.shape[1]
+    h = torch.empty(B, F_ * D + tail, dtype=e.dtype, device=e.device)
+    h[:, :F_ * D].view(B, F_, D).copy_(e[:, :, :D])
+    h[:, F_ * D:F_ * D + nd].copy_(dense)
+    if tail > nd:
+        h[:, F_ * D + nd:].zero_()
+    return h, e[:, :, D].float().sum(1, keepdim=True)
+
+
+def merge_rows_reference(d_h, d_wide, shape, D, dtype=None):
+    """Gradient of :func:`split_rows_reference` w.r.t. ``e`` (either incoming gradient may be None)."""
+    B, F_, W = shape
+    src = d_h if d_h is not None else d_wide
+    dt = dtype or src.dtype
+    de = torch.empty(B, F_, W, dtype=dt, device=src.device)
+    # three slice writes into one buffer (a concatenation along the short last axis runs at a third of the rate)
+    if d_h is not None:
+        de[:, :, :D].copy_(d_h[:, :F_ * D].view(B, F_, D))
+    else:
+        de[:, :, :D].zero_()
+    if d_wide is not None:
+        de[:, :, D:D + 1].copy_(d_wide.to(dt).reshape(B, 1, 1).expand(B, F_, 1))
+    else:
+        de[:, :, D:D + 1].zero_()
+    if W - D - 1 > 0:
+        de[:, :, D + 1:].zero_()
+    return de
+
+
+def split_kernel_eligible(e, dense, D, tail):
+    if not (_SPLIT and e.is_cuda and e.dtype == torch.bfloat16 and dense.dtype == torch.bfloat16 and e.dim() == 3
+            and e.is_contiguous() and dense.is_contiguous() and dense.shape[0] == e.shape[0]):
+        return False
+    B, F_, W = e.shape
+    return int(_lib().dtf_emb_split_ok(B, F_, D, W, dense.shape[1], tail, F_ * D + tail)) == 0
+
+
+def split_rows(e, dense, D, tail):
+    """Kernel form of :func:`split_rows_reference` (one pass: ``rowsplit_kernels.hip``)."""
+    if not split_kernel_eligible(e, dense, D, tail):
+        return split_rows_reference(e, dense, D, tail)
+    B, F_, W = e.shape
+    ldh = F_ * D + tail
+    h = torch.empty(B, ldh, dtype=e.dtype, device=e.device)
+    wide = torch.empty(B, 1, dtype=torch.float32, device=e.device)
+    rc = _lib().dtf_emb_split_fwd(hip.ptr(e), hip.ptr(dense), hip.ptr(h), hip.ptr(wide), B, F_, D, dense.shape[1], tail,
+                                  ldh, hip.stream())
+    hip.check(rc, "dtf_emb_split_fwd")
+    return h, wide
+
+
+def merge_rows(d_h, d_wide, shape, D, dtype=None):
+    """Kernel form of :func:`merge_rows_reference` (``dtype``: that of the forward's ``e``)."""
+    B, F_, W = shape
+    src = d_h if d_h is not None else d_wide
+    ok = (_SPLIT and src is not None and src.is_cuda and W == D + 8 and D % 8 == 0 and dtype in (None, torch.bfloat16)
+          and (d_h is None or (d_h.dtype == torch.bfloat16 and d_h.dim() == 2 and d_h.stride(1) == 1
+                               and d_h.stride(0) % 8 == 0 and d_h.stride(0) >= F_ * D and d_h.data_ptr() % 16 == 0))
+          and (d_wide is None or (d_wide.dtype == torch.float32 and d_wide.numel() == B and d_wide.is_contiguous())))
+    if not ok:
+        return merge_rows_reference(d_h, d_wide, shape, D, dtype)
+    de = torch.empty(B, F_, W, dtype=torch.bfloat16, device=src.device)
+    rc = _lib().dtf_emb_split_bwd(hip.ptr(d_h), hip.ptr(d_wide), hip.ptr(de), B, F_, D,
+                                  d_h.stride(0) if d_h is not None else 0, hip.stream())
+    hip.check(rc, "dtf_emb_split_bwd")
+    return de

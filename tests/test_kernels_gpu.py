@@ -340,6 +340,33 @@ def test_embedding_sgd_atomic(dev):
     torch.testing.assert_close(t1, t2, rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("B,F,D,nd,kpad", [(4096, 26, 64, 13, 19), (257, 3, 64, 0, 0), (1000, 26, 64, 13, 51), (64, 5, 16, 8, 0)])
+def test_embedding_row_split_and_merge(dev, B, F, D, nd, kpad):
+    """K20 (rowsplit_kernels.hip): fused rows -> deep-tower input + wide sums, and the gradient back, against the
+    tensor-expression definitions."""
+    from distributed_tensorflow_amd.ops import embedding as E
+
+    torch.manual_seed(2)
+    e = torch.randn(B, F, D + 8, device=dev).to(torch.bfloat16)
+    dense = torch.randn(B, nd, device=dev).to(torch.bfloat16)
+    tail = nd + kpad
+    assert E.split_kernel_eligible(e, dense, D, tail)
+    h, wide = E.split_rows(e, dense, D, tail)
+    h_ref, wide_ref = E.split_rows_reference(e, dense, D, tail)
+    assert torch.equal(h, h_ref)
+    torch.testing.assert_close(wide, wide_ref, rtol=1e-5, atol=1e-5)
+    d_h = torch.randn(B, F * D + tail, device=dev).to(torch.bfloat16)
+    d_wide = torch.randn(B, 1, device=dev)
+    for gh, gw in ((d_h, d_wide), (d_h, None), (None, d_wide)):
+        de = E.merge_rows(gh, gw, e.shape, D, torch.bfloat16)
+        assert torch.equal(de, E.merge_rows_reference(gh, gw, e.shape, D, torch.bfloat16))
+    # a row-strided gradient (a column slice of a wider buffer) is read in place
+    wide_buf = torch.randn(B, F * D + tail + 64, device=dev).to(torch.bfloat16)
+    view = wide_buf[:, :F * D + tail]
+    assert torch.equal(E.merge_rows(view, d_wide, e.shape, D, torch.bfloat16),
+                       E.merge_rows_reference(view, d_wide, e.shape, D, torch.bfloat16))
+
+
 def test_wide_deep_trains_on_gpu(dev):
     from distributed_tensorflow_amd.models import wide_deep as wd
     from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
