@@ -32,6 +32,8 @@ def _lib():
         hip.declare("dtf_embedding_segment_plan", [P, L, I, P, P, P, P, P, P])
         hip.declare("dtf_embedding_route", [P, L, I, I, L, L, L, P, P, P, P, P, P, P])
         hip.declare("dtf_route_tile", [])
+        hip.declare("dtf_sort_ids_temp_bytes", [L, L], L)
+        hip.declare("dtf_sort_ids", [P, P, P, L, L, P, L, P])
         hip.declare("dtf_emb_split_ok", [L, I, I, I, I, I, L])
         hip.declare("dtf_emb_split_fwd", [P, P, P, P, L, I, I, I, I, L, P])
         hip.declare("dtf_emb_split_bwd", [P, P, P, L, I, I, L, P])
@@ -100,13 +102,43 @@ def sparse_apply_reference(table, acc, idx, grad, opt="sgd", lr=0.01, eps=1e-10,
     table[uniq] = w.to(table.dtype)
 
 
-def segment_plan(idx, chunk):
+_SORT_KERNEL = os.environ.get("DTF_EMB_SORT_KERNEL", "1") != "0"      # A/B switch: 0 = torch.sort (all 64 key bits)
+_sort_ws = {}
+
+
+def sort_ids(idx, rows=None):
+    """Stable ascending sort of the row ids with their positions -> ``(sorted_ids, perm)``.  On the GPU with a known
+    table height ``rows``: rocPRIM's radix sort over only the ``floor(log2 rows) + 1`` key bits a row id can have
+    (``csrc/sort_kernels.hip``; 3 passes instead of 8 for config #3's 2.6 M rows); ids outside ``[0, rows)`` -- padding
+    slots -- come out as the key ``rows``, after every valid id (the apply kernels skip both forms)."""
+    flat = idx.reshape(-1)
+    n = flat.numel()
+    if not (_SORT_KERNEL and flat.is_cuda and rows and flat.dtype == torch.int64 and 0 < n < (1 << 31) - 4096):
+        return torch.sort(flat, stable=True)
+    flat = flat.contiguous()
+    lib = _lib()
+    need = int(lib.dtf_sort_ids_temp_bytes(n, int(rows)))
+    if need < 0:
+        return torch.sort(flat, stable=True)
+    key = (flat.device, torch.cuda.current_stream(flat.device).cuda_stream)
+    ws = _sort_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _sort_ws[key] = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=flat.device)
+    out = torch.empty(2, n, dtype=torch.int64, device=flat.device)
+    rc = lib.dtf_sort_ids(hip.ptr(flat), hip.ptr(out[0]), hip.ptr(out[1]), n, int(rows), hip.ptr(ws), ws.numel(),
+                          hip.stream())
+    hip.check(rc, "dtf_sort_ids")
+    return out[0], out[1]
+
+
+def segment_plan(idx, chunk, rows=None):
     """Sort ids and describe their runs with fixed-size tensors (no host sync):
     ``sorted_ids, perm, chunk_begin[n+1], seg_begin[n+1], seg_first_chunk[n+1], nchunks[1]``.
-    On the GPU the run / chunk boundaries come from the plan kernels of ``embedding_kernels.hip``."""
+    On the GPU the run / chunk boundaries come from the plan kernels of ``embedding_kernels.hip``; ``rows`` (the
+    table height) lets the sort skip the key bits no row id has."""
     n = idx.numel()
     dev = idx.device
-    sid, perm = torch.sort(idx.reshape(-1), stable=True)
+    sid, perm = sort_ids(idx, rows)
     if idx.is_cuda and _PLAN_KERNEL and 0 < n < (1 << 31) - 4096:
         lib = _lib()
         scratch = torch.empty(int(lib.dtf_embedding_plan_scratch_ints(n)), dtype=torch.int32, device=dev)
@@ -175,7 +207,7 @@ def embedding_sparse_apply(table, acc, idx, grad, opt="sgd", lr=0.01, eps=1e-10,
         hip.check(rc, "dtf_embedding_sgd_atomic")
         return
     chunk = int(lib.dtf_embedding_chunk_rows())
-    sid, perm, chunk_begin, seg_begin, seg_first_chunk, nchunks = segment_plan(idx, chunk)
+    sid, perm, chunk_begin, seg_begin, seg_first_chunk, nchunks = segment_plan(idx, chunk, rows=R)
     partial = _workspace(table.device, n * D)
     rc = lib.dtf_embedding_sparse_apply(
         hip.ptr(table), hip.dt(table), hip.ptr(acc), hip.ptr(grad), hip.dt(grad), hip.ptr(sid), hip.ptr(perm),

@@ -340,6 +340,25 @@ def test_embedding_sgd_atomic(dev):
     torch.testing.assert_close(t1, t2, rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("n,rows", [(1, 5), (1000, 7), (100003, 2600000), (1 << 20, 1 << 20), (50000, 312000000)])
+def test_sort_ids_restricted_bits_matches_stable_sort(dev, n, rows):
+    """csrc/sort_kernels.hip: radix sort over the key bits a row id can have == torch's stable sort, positions
+    included; padding ids (-1, anything >= rows) come out as the key ``rows`` behind every valid id."""
+    from distributed_tensorflow_amd.ops import embedding as E
+
+    g = torch.Generator().manual_seed(n)
+    ids = (rows * torch.rand(n, generator=g).pow(3.0)).long().clamp_(0, rows - 1)
+    if n >= 1000:
+        ids[::97] = -1
+        ids[5::211] = rows + 3
+    ids = ids.to(dev)
+    sid, perm = E.sort_ids(ids, rows)
+    folded = torch.where((ids < 0) | (ids >= rows), torch.full_like(ids, rows), ids)
+    ref_sid, ref_perm = torch.sort(folded, stable=True)
+    assert torch.equal(sid, ref_sid) and torch.equal(perm, ref_perm)
+    assert sid.dtype == torch.int64 and perm.dtype == torch.int64
+
+
 @pytest.mark.parametrize("B,F,D,nd,kpad", [(4096, 26, 64, 13, 19), (257, 3, 64, 0, 0), (1000, 26, 64, 13, 51), (64, 5, 16, 8, 0)])
 def test_embedding_row_split_and_merge(dev, B, F, D, nd, kpad):
     """K20 (rowsplit_kernels.hip): fused rows -> deep-tower input + wide sums, and the gradient back, against the
