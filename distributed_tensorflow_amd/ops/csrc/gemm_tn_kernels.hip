@@ -214,9 +214,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(TnArgs a) {
             ha[i] = tn_tr_read_2k(img + offA[i]);
         }
         if (wr == 1) TN_WAIT_NEXT(t);
+        // the reads are RETIRED before the barrier, not only issued: the other wave group restages this buffer right
+        // after it (stage(t + 4) at the top of its next iteration).  With the wait behind the barrier the kernel was
+        // correct alone and wrong under load: next to the compute stream's kernels (ops/streams.py) 10-28 of ResNet-50's
+        // 1x1 weight gradients differed from run to run by 1e-3 .. 2e-2 (scripts/determinism_check.py)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         tn_s16x8 fa[NI], fb[4];
 #pragma unroll

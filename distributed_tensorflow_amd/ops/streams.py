@@ -18,10 +18,12 @@ import os
 import torch
 
 ENABLED = os.environ.get("DTF_WGRAD_STREAM", "1") != "0"
+_DEBUG = int(os.environ.get("DTF_WGRAD_DEBUG", "0"))      # bisecting aid: 1 fresh event per call, 2 rejoin after every call
 _streams = {}
 _join_queued = set()
 _held = {}          # (device index, stream) -> tensors the side stream may still be reading
 _events = {}
+_checks = []
 
 
 def wgrad_stream(device, create=True):
@@ -59,11 +61,14 @@ def run_wgrad(fn, weight, *inputs):
     key = (dev.index, cur.cuda_stream)
     # host cost matters (ResNet-152's step is ~95 % host enqueue time): one reused event instead of the fresh one
     # ``wait_stream`` creates, ``set_stream`` instead of the ``torch.cuda.stream`` context manager
-    ev = _events.get(key)
-    if ev is None:
-        ev = _events[key] = torch.cuda.Event()
-    ev.record(cur)
-    side.wait_event(ev)
+    if _DEBUG == 1:
+        side.wait_stream(cur)               # a fresh event per call
+    else:
+        ev = _events.get(key)
+        if ev is None:
+            ev = _events[key] = torch.cuda.Event()
+        ev.record(cur)
+        side.wait_event(ev)
     if key not in _join_queued:
         # once per backward pass: when the engine is done, the stream backward ran on waits for the side stream
         _join_queued.add(key)
@@ -71,6 +76,14 @@ def run_wgrad(fn, weight, *inputs):
         def _rejoin(cur=cur, side=side, key=key):
             _join_queued.discard(key)
             cur.wait_stream(side)
+            if _DEBUG == 3:
+                torch.cuda.synchronize()
+                for copies, orig, shapes in _checks:
+                    for c, o, sh in zip(copies, orig, shapes):
+                        if not torch.equal(c, o):
+                            print("[wgrad debug] operand %s changed during backward (%.3g of its elements)" % (
+                                tuple(sh), float((c != o).float().mean())), flush=True)
+                _checks.clear()
             _held.pop(key, None)        # freed in stream order AFTER the wait: safe for the allocator to reuse
 
         try:
@@ -84,10 +97,15 @@ def run_wgrad(fn, weight, *inputs):
                 torch.cuda.set_stream(cur)
             cur.wait_stream(side)
             return out
+    if _DEBUG == 3:
+        # were the operands still the same when backward ended?  (copies taken on the compute stream first)
+        _checks.append((tuple(i.clone() for i in inputs), inputs, tuple(i.shape for i in inputs)))
     torch.cuda.set_stream(side)
     try:
         out = fn()
     finally:
         torch.cuda.set_stream(cur)
     _held.setdefault(key, []).append(inputs)
+    if _DEBUG == 2:
+        cur.wait_stream(side)               # side stream, but no overlap with what follows
     return out
