@@ -80,6 +80,13 @@ def _mm_dgrad(dy, weight):
         return bool(shapes) and ("nn", cin, dy.shape[0] * dy.shape[2] * dy.shape[3], cout) in shapes
     return False
 
+# DTF_DETERMINISTIC (default 1): every weight gradient an own kernel can compute goes through it (K6T / K6T-conv / K14 /
+# K19: fp32 slabs summed in a fixed order) instead of MIOpen's atomic-accumulating kernels -- ResNet-50's gradients are
+# then bitwise reproducible run to run on the GPU (scripts/determinism_check.py at batch 256: 0 of 161 tensors differ;
+# 3 with =0: the 64 -> 64 and 256 -> 128 1x1 layers at 56 x 56 and the first stride-2 3x3, which standalone are a little
+# faster in MIOpen).  On the weight-gradient stream the difference does not reach the step: 20.33-20.40 vs 20.38-20.40 ms
+# ResNet-50, 27.81 vs 27.75 Inception-v3, 47.83 vs 47.94 ResNet-152 (scripts/gpu_r3_ag.sh).
+_DETERMINISTIC = os.environ.get("DTF_DETERMINISTIC", "1") != "0"
 _TN_WRW_MIN_C = int(os.environ.get("DTF_CONV1X1_TN_MIN_C", "192"))      # K6T weight gradient when min(Cin, Cout) >= this
 _TN_WRW = os.environ.get("DTF_CONV1X1_TN", "1") != "0"
 _ENABLED = os.environ.get("DTF_CONV1X1_MM", "1") != "0"      # A/B switch: 0 = everything through MIOpen
@@ -149,7 +156,7 @@ def _wrw(dy, x, weight):
             return _as_filter1x1(wrw_stream(dy2, x2))
     # measured (scripts/wrw1x1_bench.py): K6T wins from 128 channels on both sides up to ~2.6e5 pixels (ResNet's 28x28
     # and Inception's 17x17 / 8x8 stages), from 192 channels beyond; the 56x56 layers are HBM-bound and MIOpen's
-    if _TN_WRW and (min(cin, cout) >= _TN_WRW_MIN_C
+    if _TN_WRW and (_DETERMINISTIC or min(cin, cout) >= _TN_WRW_MIN_C
                     or (min(cin, cout) >= 128 and dy.shape[0] * dy.shape[2] * dy.shape[3] <= 262144)):
         from .linear import gemm_tn, gemm_tn_eligible
 
@@ -617,7 +624,7 @@ def conv_wrw_direct_ok(x, weight, stride, padding):
 
 def conv_wrw_profitable(weight, x=None, stride=(1, 1), padding=(1, 1)):
     """Where the module form switches to K6T / K14 on its own (``conv_wrw`` itself runs any eligible shape)."""
-    if min(weight.shape[0], weight.shape[1]) >= _CONV_WRW_MIN_CH:
+    if _DETERMINISTIC or min(weight.shape[0], weight.shape[1]) >= _CONV_WRW_MIN_CH:
         return True
     return x is not None and conv_wrw_direct_ok(x, weight, stride, padding)
 

@@ -338,3 +338,30 @@ for name, c in cases:
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok ") == 4, r.stdout
+
+
+def test_resnet50_gradients_are_bitwise_reproducible(dev):
+    """Sync-mode training is bitwise reproducible on the GPU: with the weight gradients on their side
+    stream and every one of them in an own fixed-order kernel (DTF_DETERMINISTIC, the default), four backward passes
+    over the same batch give identical gradients for all 161 tensors."""
+    from distributed_tensorflow_amd.models import resnet
+    from distributed_tensorflow_amd.ops import conv as conv_ops
+    from distributed_tensorflow_amd.ops import streams
+
+    if not conv_ops._DETERMINISTIC:
+        pytest.skip("DTF_DETERMINISTIC=0")
+    torch.manual_seed(0)
+    m = resnet.prepare(resnet.build(), torch.device(dev)).train()
+    batch = resnet.synthetic_batch(64, device=dev, seed=1)
+    ref = None
+    for it in range(4):
+        for p in m.parameters():
+            p.grad = None
+        resnet.loss_fn(m, batch).backward()
+        torch.cuda.synchronize()
+        g = {n: p.grad.clone() for n, p in m.named_parameters()}
+        if ref is not None:
+            diff = [n for n in g if not torch.equal(g[n], ref[n])]
+            assert not diff, "iteration %d: %d tensors differ: %s" % (it, len(diff), diff[:6])
+        ref = g
+    assert streams.ENABLED and streams.wgrad_stream(torch.device(dev), create=False) is not None
