@@ -7,11 +7,13 @@ from distributed_tensorflow_amd.utils import gemm_tuning
 gemm_tuning.setup()
 import torch
 gemm_tuning.after_torch_import()
-from distributed_tensorflow_amd.models import resnet
+from distributed_tensorflow_amd.models import get_model_module
 
+# usage: determinism_check.py [batch] [model]   (model: resnet50 (default), inception_v3, bert)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+resnet = get_model_module(sys.argv[2] if len(sys.argv) > 2 else "resnet50")
 m = resnet.prepare(resnet.build(), dev).train()
 batch = resnet.synthetic_batch(B, device=dev, seed=1)
 ref = None
