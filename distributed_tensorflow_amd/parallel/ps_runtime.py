@@ -225,6 +225,7 @@ class ShardedPS:
         self._pull_events = [torch.cuda.Event() for _ in range(nb)] if self.is_cuda else [None] * nb
         self._pull_pending = [False] * nb     # pulled on the comm stream, not yet waited for by the compute stream
         self._prefetch = False                # per-bucket waits are live (attach + one learning step done)
+        self._grad_keep = []                  # gradients of earlier steps whose packs this stream has not waited for yet
         self.prefetch_waits = 0               # per-bucket event waits issued so far (tests / diagnostics)
         self._attached = None
 
@@ -574,6 +575,18 @@ class ShardedPS:
     def _finish_step(self):
         if self._unpack_needed:
             self._unpack_params()
+        if self.comm_stream is not None and (self._prefetch or self.update_mode == "stale"):
+            # The packs read p.grad on the comm stream, and in these two modes this stream does NOT wait for the comm
+            # stream before it goes on: the caching allocator would hand a freed gradient's block (the BatchNorm
+            # gradients live in the compute stream's pool) to the next forward's first allocations while the tail
+            # bucket's pack is still queued.  Measured: ResNet-50, live 1-rank group, loss after 48 steps 4.3307 with the
+            # prefetch against 4.6683 with the global join and without a communicator (scripts/gpu_r3_ak.sh).  The
+            # tensors are kept until this stream HAS waited for those packs: the next forward waits for every pull
+            # event (sync), the slot wait `staleness` steps later (stale).
+            self._grad_keep.append([p.grad for p in self.params])
+            del self._grad_keep[:-max(1, self.staleness if self.update_mode == "stale" else 1)]
+        else:
+            self._grad_keep.clear()
         for p in self.params:
             p.grad = None
         self._pending = [len(b.params) for b in self.layout.buckets]
@@ -586,6 +599,7 @@ class ShardedPS:
         nb = len(self.layout.buckets)
         for p in self.params:
             p.grad = None
+        self._grad_keep.clear()
         self._pending = [len(b.params) for b in self.layout.buckets]
         self._launched = [False] * nb
         self._pushed = [None] * nb
@@ -618,7 +632,12 @@ class ShardedPS:
     def set_lr(self, lr):
         if lr != self._lr:
             self._lr = float(lr)
-            self.hyper[0:1].fill_(self._lr)
+            # on the comm stream: the shard applies read the value there, and with the pull prefetch or the stale
+            # pipeline the previous step's applies may still be queued when the schedule sets the next step's rate --
+            # a fill on the compute stream raced with them (ResNet-50 with the bench's warm-up schedule: the tail
+            # bucket's apply of step t used the rate of step t + 1, loss after 48 steps 4.3307 against 4.6683)
+            with self._on_comm_stream():
+                self.hyper[0:1].fill_(self._lr)
 
     @property
     def lr(self):
