@@ -87,6 +87,7 @@ def _mm_dgrad(dy, weight):
 # faster in MIOpen).  On the weight-gradient stream the difference does not reach the step: 20.33-20.40 vs 20.38-20.40 ms
 # ResNet-50, 27.81 vs 27.75 Inception-v3, 47.83 vs 47.94 ResNet-152 (scripts/gpu_r3_ag.sh).
 _DETERMINISTIC = os.environ.get("DTF_DETERMINISTIC", "1") != "0"
+_DETERMINISTIC_STRICT = os.environ.get("DTF_DETERMINISTIC", "1") == "2"      # also the image-input layers (see _ConvFn)
 _TN_WRW_MIN_C = int(os.environ.get("DTF_CONV1X1_TN_MIN_C", "192"))      # K6T weight gradient when min(Cin, Cout) >= this
 _TN_WRW = os.environ.get("DTF_CONV1X1_TN", "1") != "0"
 _ENABLED = os.environ.get("DTF_CONV1X1_MM", "1") != "0"      # A/B switch: 0 = everything through MIOpen
@@ -594,11 +595,12 @@ def _wrw_lib():
     return lib
 
 
-def conv_wrw_eligible(dy, x, weight, stride, padding, dilation=(1, 1), groups=1):
+def conv_wrw_eligible(dy, x, weight, stride, padding, dilation=(1, 1), groups=1, min_k=256):
+    # min_k: below one 256-wide K tile the kernel works (columns past K read the zero page) but wastes most of its tile
     return (_CONV_WRW and x.is_cuda and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
             and weight.dtype == torch.bfloat16 and x.dim() == 4 and groups == 1 and tuple(dilation) == (1, 1)
             and stride[0] == stride[1] and x.shape[1] % 8 == 0 and weight.shape[0] % 8 == 0
-            and weight.shape[1] * weight.shape[2] * weight.shape[3] >= 256
+            and weight.shape[1] * weight.shape[2] * weight.shape[3] >= min_k
             and x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last)
             and weight.is_contiguous(memory_format=torch.channels_last)
             and dy.shape[0] * dy.shape[2] * dy.shape[3] < (1 << 24))
@@ -867,6 +869,30 @@ class _ConvFn(torch.autograd.Function):
         use_tn = (ctx.needs_input_grad[1] and _CONV_WRW and conv_wrw_profitable(weight, x, stride, padding)
                   and conv_wrw_eligible(dy, x, weight, stride, padding))
         use_fwd = ctx.needs_input_grad[0] and _dgrad_as_fwd_ok(x, weight, stride, padding)
+        if (_DETERMINISTIC_STRICT and ctx.needs_input_grad[1] and not use_tn and _CONV_WRW and weight.shape[1] < 8
+                and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
+            # an image-input layer (3 channels; Inception-v3's 3x3 / 2 stem): no own kernel takes fewer than 8 input
+            # channels and MIOpen's weight gradient accumulates with atomics -- the one tensor of Inception-v3 that
+            # differed run to run.  DTF_DETERMINISTIC=2 pads the input to 8 zero-filled channels (one extra pass over
+            # the image) and lets K6T-conv compute the 8-channel gradient; the first `cin` channels are the answer.
+            # Not the default: a 72-wide K in a 256-wide tile is slow (Inception-v3 28.5 vs 27.5 ms/step, -3.7 %).
+            cin = weight.shape[1]
+            xp = torch.empty((x.shape[0], 8, x.shape[2], x.shape[3]), dtype=x.dtype, device=x.device,
+                             memory_format=torch.channels_last).zero_()
+            wp = torch.empty((weight.shape[0], 8, weight.shape[2], weight.shape[3]), dtype=weight.dtype,
+                             device=weight.device, memory_format=torch.channels_last)
+            if conv_wrw_eligible(dy, xp, wp, stride, padding, min_k=0):
+                def padded_wrw():
+                    xp[:, :cin].copy_(x)
+                    return conv_wrw(dy, xp, wp, stride, padding)[:, :cin].contiguous(memory_format=torch.channels_last)
+
+                dw = _streams.run_wgrad(padded_wrw, weight, dy, x, xp)
+                if ctx.needs_input_grad[0] and not use_fwd:
+                    dx, _, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, list(stride), list(padding),
+                                                                   [1, 1], False, [0, 0], 1, [True, False, False])
+                elif use_fwd:
+                    dx = dgrad_as_forward(dy, weight, padding)
+                return dx, dw, None, None, None
         mask = [ctx.needs_input_grad[0] and not use_fwd, ctx.needs_input_grad[1] and not use_tn, False]
         if mask[0] and mask[1] and _streams.ENABLED:
             # the library's data gradient on this stream, its weight gradient on the side stream

@@ -1001,6 +1001,35 @@ def test_conv_wrw_matches_reference(dev, cfg, monkeypatch):
     assert float((x3.grad.float() - x2.grad).norm() / x2.grad.norm()) < 2e-2
 
 
+@pytest.mark.parametrize("NB,H,W,Cout,k,stride,pad", [(16, 75, 75, 32, 3, 2, 0), (4, 64, 48, 64, 7, 2, 3), (8, 33, 33, 32, 3, 1, 1)])
+def test_image_input_conv_weight_gradient_is_deterministic(dev, NB, H, W, Cout, k, stride, pad, monkeypatch):
+    """A 3-channel (image input) convolution with DTF_DETERMINISTIC=2: the weight gradient comes from K6T-conv over the
+    input padded to 8 channels -- matches conv2d's gradient, the data gradient still comes out, and two passes are
+    bitwise equal (MIOpen's kernel for these layers accumulates with atomics)."""
+    from distributed_tensorflow_amd.ops import conv
+
+    monkeypatch.setattr(conv, "_DETERMINISTIC_STRICT", True)        # DTF_DETERMINISTIC=2
+    torch.manual_seed(4)
+    m = conv.Conv2dTN(3, Cout, k, stride=stride, padding=pad, bias=False).to(dev).to(torch.bfloat16)
+    m = m.to(memory_format=torch.channels_last)
+    x = torch.randn(NB, 3, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x2, w2 = x.float().requires_grad_(), m.weight.detach().float().requires_grad_()
+    y2 = torch.nn.functional.conv2d(x2, w2, None, stride, pad)
+    dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y2.backward(dy.float())
+    grads = []
+    for _ in range(2):
+        m.weight.grad = None
+        x3 = x.clone().requires_grad_()
+        m(x3).backward(dy)
+        torch.cuda.synchronize()
+        grads.append(m.weight.grad.clone())
+        assert float((x3.grad.float() - x2.grad).norm() / x2.grad.norm()) < 2e-2
+    assert grads[0].shape == m.weight.shape
+    assert float((grads[0].float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
+    assert torch.equal(grads[0], grads[1])
+
+
 @pytest.mark.parametrize("n,rows,chunk", [(1, 10, 64), (1000, 50, 64), (5000, 3, 64), (70000, 100000, 64), (300001, 7, 64),
                                           (4096, 1, 5), (2048, 2048 * 4, 64), (1025, 40, 3)])
 def test_segment_plan_kernel_matches_framework_ops(dev, n, rows, chunk):
