@@ -814,6 +814,67 @@ def test_gemm_tn_is_bitwise_stable_next_to_other_kernels(dev, M, N, K):
     assert bad == 0, "%d of 12 overlapped runs differ from the run alone" % bad
 
 
+def _overlap_cases(dev):
+    """(name, closure) of every own kernel with an LDS-DMA / multi-buffer pipeline, on shapes of the models."""
+    from distributed_tensorflow_amd.ops import attention, conv
+    from distributed_tensorflow_amd.ops.linear import gemm_bias_act
+
+    def cl(*shape):
+        return torch.randn(*shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    torch.manual_seed(21)
+    cases = []
+    x64, w64 = cl(32, 64, 56, 56), (cl(64, 64, 3, 3) * 0.05)
+    dy64 = cl(32, 64, 56, 56)
+    cases.append(("K16 conv3x3 64->64 forward", lambda: conv.conv_fwd(x64, w64, (1, 1), (1, 1))))
+    cases.append(("K14 direct 3x3 weight gradient", lambda: conv.conv_wrw(dy64, x64, w64, (1, 1), (1, 1))))
+    x256, w256 = cl(32, 256, 14, 14), (cl(256, 256, 3, 3) * 0.02)
+    dy256 = cl(32, 256, 14, 14)
+    cases.append(("K13 conv3x3 256->256 forward", lambda: conv.conv_fwd(x256, w256, (1, 1), (1, 1))))
+    cases.append(("K6T-conv 3x3 weight gradient", lambda: conv.conv_wrw(dy256, x256, w256, (1, 1), (1, 1))))
+    a256, b64 = cl(64, 256, 56, 56), cl(64, 64, 56, 56)
+    cases.append(("K19 streaming 1x1 weight gradient",
+                  lambda: conv.wrw_stream(conv._rows(a256), conv._rows(b64))))
+    w_sq = (cl(64, 256, 1, 1) * 0.05)
+    cases.append(("K18 1x1 onto 64 channels", lambda: conv.conv1x1(a256, w_sq)))
+    w_ex = (cl(256, 64, 1, 1) * 0.05)
+    cases.append(("K17 1x1 64->256 with statistics", lambda: conv.conv1x1_stats(b64, w_ex)[0]
+                  if conv.conv1x1_stats(b64, w_ex) is not None else conv.conv1x1(b64, w_ex)))
+    xg = torch.randn(8192, 768, device=dev).to(torch.bfloat16)
+    wg = (torch.randn(3072, 768, device=dev) * 0.02).to(torch.bfloat16)
+    bg = torch.zeros(3072, device=dev, dtype=torch.bfloat16)
+    cases.append(("K6 GEMM bias + ReLU", lambda: gemm_bias_act(xg, wg, bg, "relu")[0]))
+    qkv = torch.randn(8, 512, 3, 12, 64, device=dev).to(torch.bfloat16)
+    cases.append(("K11 attention forward", lambda: attention.attn_fwd_packed(qkv)[0]))
+    return cases
+
+
+def test_pipelined_kernels_are_bitwise_stable_next_to_other_kernels(dev):
+    """Every own kernel with a multi-buffer LDS pipeline, launched on a second stream while BatchNorm passes (HBM +
+    LDS traffic, co-resident blocks) run on the first, computes bitwise what it computes alone -- the property whose
+    absence in K6T (a wait on the wrong side of a barrier) no single-stream numerics test could see."""
+    x = torch.randn(64, 256, 56, 56, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.ones(256, device=dev, dtype=torch.bfloat16)
+    bias = torch.zeros(256, device=dev, dtype=torch.bfloat16)
+    side = torch.cuda.Stream()
+    failures = []
+    for name, fn in _overlap_cases(dev):
+        ref = fn()
+        torch.cuda.synchronize()
+        bad = 0
+        for _ in range(8):
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = fn()
+            for _ in range(2):
+                batchnorm.fused_bn_act(x, w, bias, None, None, None, True, 0.1, 1e-5, True)
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(out, ref))
+        if bad:
+            failures.append("%s: %d of 8 overlapped runs differ" % (name, bad))
+    assert not failures, "; ".join(failures)
+
+
 def test_gemm_tn_identity_layout(dev):
     """A = I: C = A^T B must reproduce an asymmetric B exactly (catches transposed / permuted fragment maps)."""
     M = N = 1024
