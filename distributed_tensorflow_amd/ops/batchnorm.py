@@ -44,9 +44,17 @@ def _lib():
 _partial_ws = {}
 
 
-def _partial(device, M, C):
-    need = int(_lib().dtf_bn_partial_floats(M, C))
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+_partial_need = {}
+
+
+def _partial(device, M, C, stream=None):
+    """Per-stream scratch for the reduction partials.  ``stream``: the raw handle of the current stream when the
+    caller has it already (host time matters here: 100-300 BatchNorm calls per step, a deep ResNet's step is bound by
+    host enqueue time -- the size query is cached, the stream looked up once per call)."""
+    need = _partial_need.get((M, C))
+    if need is None:
+        need = _partial_need[(M, C)] = int(_lib().dtf_bn_partial_floats(M, C))
+    key = (device, torch.cuda.current_stream(device).cuda_stream if stream is None else stream)
     ws = _partial_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=device)
@@ -54,14 +62,24 @@ def _partial(device, M, C):
     return ws
 
 
+_mask_need = {}
+
+
+def _mask_bytes(M, C):
+    n = _mask_need.get((M, C))
+    if n is None:
+        n = _mask_need[(M, C)] = int(_lib().dtf_bn_mask_bytes(M, C))
+    return n
+
+
 _ticket_ws = {}
 
 
-def _tickets(device):
+def _tickets(device, stream=None):
     """Zeroed ticket counters of the calling stream for the backward reduce kernels' fused finalize (``BnFin`` in
     csrc/bn_kernels.hip): the kernels leave them zero again, kernels of one stream run in order, and a second stream
     gets counters of its own."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, torch.cuda.current_stream(device).cuda_stream if stream is None else stream)
     t = _ticket_ws.get(key)
     if t is None:
         t = _ticket_ws[key] = torch.zeros(64, dtype=torch.int32, device=device)
@@ -154,21 +172,22 @@ class _FusedBNAct(torch.autograd.Function):
         if residual is not None:
             assert residual.shape == x.shape and residual.dtype == x.dtype and _nhwc_rows(residual) is not None
             if relu:
-                mask = torch.empty(int(lib.dtf_bn_mask_bytes(M, C)), dtype=torch.uint8, device=dev)
+                mask = torch.empty(_mask_bytes(M, C), dtype=torch.uint8, device=dev)
+        sp, st = stats.data_ptr(), hip.stream()          # rows of `stats` by address: no four view tensors per call
         if pre is not None:
             assert ldx == C
             assert pre.dtype == torch.float32 and pre.dim() == 3 and pre.shape[1] == 2 and pre.shape[2] == C and pre.is_contiguous()
             rc = lib.dtf_bn_fwd_train_pre(
                 hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
                 hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
-                stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-                hip.ptr(pre), int(pre.shape[0]), M, C, int(relu), 0, hip.stream())
+                sp, sp + 4 * C, sp + 8 * C, sp + 12 * C,
+                hip.ptr(pre), int(pre.shape[0]), M, C, int(relu), 0, st)
         else:
             rc = lib.dtf_bn_fwd_train(
                 hip.ptr(x), hip.ptr(residual), hip.ptr(y), hip.ptr(mask), hip.ptr(weight), hip.ptr(bias), hip.dt(weight),
                 hip.ptr(running_mean), hip.ptr(running_var), float(momentum), float(eps),
-                stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-                hip.ptr(_partial(dev, M, C)), M, C, int(relu), 0, ldx, hip.stream())
+                sp, sp + 4 * C, sp + 8 * C, sp + 12 * C,
+                hip.ptr(_partial(dev, M, C, st)), M, C, int(relu), 0, ldx, st)
         hip.check(rc, "dtf_bn_fwd_train")
         ctx.save_for_backward(x, mask, weight, stats)
         # ReLU mask source for backward: 1 = recompute from x (no residual), 3 = bit mask
@@ -191,13 +210,15 @@ class _FusedBNAct(torch.autograd.Function):
         dres = torch.empty_like(dy) if ctx.has_res else None
         dgb = torch.empty(2, C, dtype=weight.dtype, device=dev)
         coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+        sp, st = stats.data_ptr(), hip.stream()
+        dg, db = dgb[0], dgb[1]
         rc = lib.dtf_bn_bwd_train(
-            hip.ptr(dy), hip.ptr(x), hip.ptr(mask), hip.ptr(weight), hip.dt(weight), stats[0].data_ptr(),
-            stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), hip.ptr(dx), hip.ptr(dres),
-            dgb[0].data_ptr(), dgb[1].data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C)), M, C,
-            int(ctx.relu_mode), 0, ctx.ldx, lddx, hip.ptr(_tickets(dev)), hip.stream())
+            hip.ptr(dy), hip.ptr(x), hip.ptr(mask), hip.ptr(weight), hip.dt(weight), sp, sp + 4 * C, sp + 8 * C,
+            sp + 12 * C, hip.ptr(dx), hip.ptr(dres),
+            dg.data_ptr(), db.data_ptr(), hip.ptr(coef), hip.ptr(_partial(dev, M, C, st)), M, C,
+            int(ctx.relu_mode), 0, ctx.ldx, lddx, hip.ptr(_tickets(dev, st)), st)
         hip.check(rc, "dtf_bn_bwd_train")
-        return dx, dgb[0], dgb[1], dres, None, None, None, None, None, None
+        return dx, dg, db, dres, None, None, None, None, None, None
 
 
 _BN2 = __import__("os").environ.get("DTF_BN2", "1") != "0"      # A/B switch for fused_bn2_add_relu
