@@ -3,6 +3,8 @@ really run (reduce_scatter / all_to_all / all_gather / all_reduce on the comm st
 hooks, bf16 wire, in-place slices), and the result must be bitwise what the collective-free path leaves.  Plus the
 numerics of the device-side embedding router against its framework-op reference."""
 import copy
+import os
+import socket
 
 import pytest
 import torch
@@ -318,3 +320,41 @@ def test_one_sided_async_ps_free_running_on_gpu(dev, tmp_path):
     fast, slow = res["steps"]
     assert fast > 2 * slow, res["steps"]
     assert res["losses"][-1] < 0.5 * res["losses"][0]
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_bench_ends_at_the_same_loss_through_every_data_plane_path():
+    """bench.py, ResNet-50 batch 64, twelve steps with the lr warm-up schedule, as separate processes: without a
+    communicator (twice: run-to-run reproducibility), through a live 1-rank RCCL group with the pull prefetch, with the
+    all-to-all push, with the native communicator, and through the one-sided async runtime -- one final loss, digit for
+    digit.  This comparison is what exposed the K6T hazard and the two prefetch races of round 3
+    (profiles/r3_path_consistency.txt)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env, *extra):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "4", "--batch", "64",
+               "--lr-warmup-steps", "10"] + list(extra)
+        e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        e.update(env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        return out["config"]["final_loss"], out["config"]["first_loss"]
+
+    ref = run({})
+    assert ref[0] == ref[0] and 0.0 < ref[0] < 20.0          # finite (lr 0.1 after 10 steps: the loss may still hump)
+    for name, env, extra in [("plain again", {}, []), ("live", {"DTF_FORCE_COMM": "1"}, []),
+                             ("live all-to-all", {"DTF_FORCE_COMM": "1"}, ["--push", "all_to_all"]),
+                             ("native", {"DTF_FORCE_COMM": "1", "DTF_COMM_BACKEND": "rccl-native"}, []),
+                             ("async", {"DTF_FORCE_COMM": "1"}, ["--update-mode", "async"])]:
+        got = run(env, *extra)
+        assert got == ref, "%s: %r vs %r" % (name, got, ref)
