@@ -8,7 +8,7 @@ mkdir -p $R/gpurun_out/$OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT -o $name -- python3 $R/scripts/$DRV 2>&1 | grep -v "^[EW]2026" | tail -2 || exit 1
+  timeout -s KILL ${PMC_TIMEOUT:-120} rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/$OUT -o $name -- python3 $R/scripts/$DRV 2>&1 | grep -v "^[EW]2026" | tail -2 || exit 1
 }
 run mfma SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE \
  && run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS \
