@@ -22,6 +22,32 @@ import torch.nn.functional as F
 
 from . import streams as _streams
 
+# Route trace ("routing maze"): while ``ROUTE_LOG`` is a list every per-product kernel choice below
+# appends ``(product, (cin, cout, kh, kw, stride), (N, H, W), choice)``.  ``route_trace()`` is the context manager,
+# ``scripts/route_table.py`` prints the table of a model, ``tests/test_models_gpu.py`` pins ResNet-50's at the bench shape.
+ROUTE_LOG = None
+
+
+def _rt(product, weight, x, stride, choice):
+    if ROUTE_LOG is not None:
+        cout, cin, kh, kw = weight.shape
+        ROUTE_LOG.append((product, (int(cin), int(cout), int(kh), int(kw), int(stride[0]) if stride else 1),
+                          (int(x.shape[0]), int(x.shape[2]), int(x.shape[3])), choice))
+
+
+class route_trace:
+    """``with route_trace() as log: loss.backward()`` -> the kernel choice of every convolution product in the block."""
+
+    def __enter__(self):
+        global ROUTE_LOG
+        self._old, ROUTE_LOG = ROUTE_LOG, []
+        return ROUTE_LOG
+
+    def __exit__(self, *exc):
+        global ROUTE_LOG
+        ROUTE_LOG = self._old
+        return False
+
 _MM_BWD_DATA_MIN_CIN = int(os.environ.get("DTF_CONV1X1_MM_DGRAD_MIN_CIN", "128"))
 _MM_FWD_MIN_CIN = int(os.environ.get("DTF_CONV1X1_MM_FWD_MIN_CIN", "1024"))
 _MM_FWD_SKIP = {int(c) for c in os.environ.get("DTF_CONV1X1_MM_FWD_SKIP", "").split(",") if c}
@@ -154,6 +180,7 @@ def _wrw(dy, x, weight):
             and dy.is_contiguous(memory_format=torch.channels_last) and x.is_contiguous(memory_format=torch.channels_last):
         dy2, x2 = _rows(dy), _rows(x)
         if wrw_stream_ok(dy2, x2):
+            _rt("wgrad", weight, x, None, "K19 streaming 1x1")
             return _as_filter1x1(wrw_stream(dy2, x2))
     # measured (scripts/wrw1x1_bench.py): K6T wins from 128 channels on both sides up to ~2.6e5 pixels (ResNet's 28x28
     # and Inception's 17x17 / 8x8 stages), from 192 channels beyond; the 56x56 layers are HBM-bound and MIOpen's
@@ -163,9 +190,24 @@ def _wrw(dy, x, weight):
 
         dy2, x2 = _rows(dy), _rows(x)
         if gemm_tn_eligible(dy2, x2) and weight.dtype == torch.bfloat16:
+            _rt("wgrad", weight, x, None, "K6T")
             return _as_filter1x1(gemm_tn(dy2, x2))
+        if _DETERMINISTIC_STRICT and weight.dtype == torch.bfloat16 and dy2.is_cuda and dy2.dtype == torch.bfloat16:
+            # K6T wants a row count that is a multiple of 32 and >= 1024 (e.g. 48 x 7 x 7 = 2352 is not): zero rows add
+            # nothing to dY^T X, so strict mode pads both operands instead of handing the product to MIOpen
+            M = dy2.shape[0]
+            Mp = max(1024, (M + 31) // 32 * 32)
+            dyp = torch.zeros(Mp, cout, dtype=dy2.dtype, device=dy2.device)
+            xp = torch.zeros(Mp, cin, dtype=x2.dtype, device=x2.device)
+            dyp[:M].copy_(dy2)
+            xp[:M].copy_(x2)
+            if gemm_tn_eligible(dyp, xp):
+                _rt("wgrad", weight, x, None, "K6T over zero-padded rows")
+                return _as_filter1x1(gemm_tn(dyp, xp))
     if _WRW_LIB and _mm_wrw(dy, weight):
+        _rt("wgrad", weight, x, None, "hipBLASLt")
         return _as_filter1x1(torch.matmul(_rows(dy).t(), _rows(x)))
+    _rt("wgrad", weight, x, None, "MIOpen")
     _, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
                                                    [0, 0], 1, [False, True, False])
     return dw
@@ -255,11 +297,19 @@ class _Conv1x1Fn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         y = _fwd_n64(x, weight)
         if y is not None:
+            _rt("fwd", weight, x, None, "K18 streaming onto 64 channels")
             return y
         if mm_fwd or _mm_fwd(x, weight):
+            _rt("fwd", weight, x, None, "hipBLASLt")
             y2 = torch.matmul(_rows(x), weight.reshape(cout, cin).t())
             N, _, H, W = x.shape
             return y2.view(N, H, W, cout).permute(0, 3, 1, 2)
+        if _DETERMINISTIC_STRICT and conv_fwd_eligible(x, weight, (1, 1), (0, 0)):
+            # a shape neither library has a recorded choice for (any batch size but the tuned ones) gets MIOpen's
+            # heuristic pick, which may accumulate with atomics (ResNet-50 at batch 32: the forward itself differed
+            # run to run); strict mode keeps such products on the own pipeline
+            return conv_fwd(x, weight, (1, 1), (0, 0))
+        _rt("fwd", weight, x, None, "MIOpen")
         return F.conv2d(x, weight)
 
     @staticmethod
@@ -273,11 +323,20 @@ class _Conv1x1Fn(torch.autograd.Function):
         if need_dx:
             dx = _dgrad_n64(dy, weight)
             need_dx = dx is None
+            if not need_dx:
+                _rt("dgrad", weight, x, None, "K18 streaming onto 64 channels")
         if need_dx and _mm_dgrad(dy, weight):
+            _rt("dgrad", weight, x, None, "hipBLASLt")
             N, _, H, W = x.shape
             dx = torch.matmul(_rows(dy), weight.reshape(cout, cin)).view(N, H, W, cin).permute(0, 3, 1, 2)
             need_dx = False
+        if need_dx and _DETERMINISTIC_STRICT:
+            wt = weight.reshape(cout, cin).t().contiguous().view(cin, 1, 1, cout).permute(0, 3, 1, 2)    # [Cin, Cout, 1, 1]
+            if conv_fwd_eligible(dy, wt, (1, 1), (0, 0)):
+                dx = conv_fwd(dy, wt, (1, 1), (0, 0), _product="dgrad")
+                need_dx = False
         if need_dx:
+            _rt("dgrad", weight, x, None, "MIOpen")
             dx, _, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1, 1], [0, 0], [1, 1], False,
                                                            [0, 0], 1, [True, False, False])
         if need_dw:
@@ -314,8 +373,9 @@ class _Conv1x1StatsFn(torch.autograd.Function):
             hip.declare("dtf_gemm_stats", [P, P, P, P, I, I, I, P])
             _stats_declared = True
         ctx.save_for_backward(x, weight)
+        _rt("fwd", weight, x, None, "K6 / K13 pipeline + BN statistics")
         if _STATS_K13:          # the same pipeline through the convolution entry point: tile picked per problem
-            y, part = conv_fwd(x, weight, (1, 1), (0, 0), stats=True)
+            y, part = conv_fwd(x, weight, (1, 1), (0, 0), stats=True, _traced=True)
             ctx.mark_non_differentiable(part)
             return y, part
         cout, cin = weight.shape[0], weight.shape[1]
@@ -356,6 +416,7 @@ class _Conv1x1K17Fn(torch.autograd.Function):
             _k17_declared = True
         ctx.save_for_backward(x, weight)
         ctx.set_materialize_grads(False)
+        _rt("fwd", weight, x, None, "K17 streaming 64 -> 256 + BN statistics")
         cout, cin = weight.shape[0], weight.shape[1]
         N, _, H, W = x.shape
         M = N * H * W
@@ -424,11 +485,15 @@ class _Conv1x1ForkFn(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         y = _fwd_n64(x, weight)
         if y is not None:
-            pass
+            _rt("fwd", weight, x, None, "K18 streaming onto 64 channels")
         elif _mm_fwd(x, weight):
+            _rt("fwd", weight, x, None, "hipBLASLt")
             N, _, H, W = x.shape
             y = torch.matmul(_rows(x), weight.reshape(cout, cin).t()).view(N, H, W, cout).permute(0, 3, 1, 2)
+        elif _DETERMINISTIC_STRICT and conv_fwd_eligible(x, weight, (1, 1), (0, 0)):
+            y = conv_fwd(x, weight, (1, 1), (0, 0))
         else:
+            _rt("fwd", weight, x, None, "MIOpen")
             y = F.conv2d(x, weight)
         return y, x.view_as(x)
 
@@ -445,6 +510,7 @@ class _Conv1x1ForkFn(torch.autograd.Function):
         if need_dx:
             N, _, H, W = x.shape
             w2 = weight.reshape(cout, cin)
+            _rt("dgrad", weight, x, None, "hipBLASLt" if dskip is None else "hipBLASLt, shortcut gradient added by beta = 1")
             if dskip is None:
                 dx2 = torch.matmul(_rows(dy), w2)
             else:
@@ -540,6 +606,7 @@ def conv1x1(x, weight, mm_fwd=False):
     if (_ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
             and weight.shape[2] == 1 and weight.shape[3] == 1):
         return _Conv1x1Fn.apply(x, weight, mm_fwd)
+    _rt("fwd + bwd", weight, x, None, "framework conv2d (MIOpen)")
     return F.conv2d(x, weight)
 
 
@@ -745,7 +812,7 @@ def conv_fwd_eligible(x, weight, stride, padding, dilation=(1, 1), groups=1):
             and weight.data_ptr() % 16 == 0 and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 31) - 256)
 
 
-def conv_fwd(x, weight, stride, padding, stats=False):
+def conv_fwd(x, weight, stride, padding, stats=False, _traced=False, _product="fwd"):
     """``conv2d(x, weight, None, stride, padding)`` for NHWC bf16 tensors on K13.  ``stats=True`` -> ``(y, partials)``
     with the fp32 ``[blocks, 2, Cout]`` column sums / sums of squares of ``y`` from the epilogue (what
     ``FusedBatchNormAct(..., stats=partials)`` finalizes instead of reading ``y`` once more)."""
@@ -765,6 +832,8 @@ def conv_fwd(x, weight, stride, padding, stats=False):
     y = torch.empty((NB, OH, OW, Cout), dtype=torch.bfloat16, device=dev)
     part = None
     if conv_c64_shape(weight, stride, padding) and lib.dtf_conv3x3_c64_ok(NB, H, W):
+        if not _traced:
+            _rt(_product, weight, x, stride, "K16 direct 64-channel 3x3" + (" + BN statistics" if stats else ""))
         if stats:
             part = torch.empty(int(lib.dtf_conv3x3_c64_blocks(NB, H, W)), 2, Cout, dtype=torch.float32, device=dev)
         rc = lib.dtf_conv3x3_c64(hip.ptr(x), hip.ptr(weight), hip.ptr(z), hip.ptr(y), hip.ptr(part) if stats else None, NB, H, W,
@@ -772,6 +841,8 @@ def conv_fwd(x, weight, stride, padding, stats=False):
         hip.check(rc, "dtf_conv3x3_c64")
         y = y.permute(0, 3, 1, 2)
         return (y, part) if stats else y
+    if not _traced:
+        _rt(_product, weight, x, stride, "K13 implicit GEMM" + (" + BN statistics" if stats else ""))
     if stats:
         part = torch.empty(int(lib.dtf_conv_fwd_stats_blocks(NB * OH * OW, Cout)), 2, Cout, dtype=torch.float32, device=dev)
     rc = lib.dtf_conv_fwd(hip.ptr(x), hip.ptr(weight), hip.ptr(z), hip.ptr(y), hip.ptr(part) if stats else None, NB, H, W, Cin,
@@ -809,8 +880,9 @@ def _dgrad_as_fwd_ok(x, weight, stride, padding):
     return weight.shape[0] == weight.shape[1] and 2 * padding[0] == kh - 1 and 2 * padding[1] == kw - 1
 
 
-def dgrad_as_forward(dy, weight, padding):
-    """``dX`` of a stride-1, dilation-1 ``conv2d(x, weight, padding=padding)``."""
+def dgrad_as_forward(dy, weight, padding, force_own=False):
+    """``dX`` of a stride-1, dilation-1 ``conv2d(x, weight, padding=padding)``.  ``force_own``: K13 wherever it is
+    eligible, also where a tuned MIOpen kernel would be faster (strict deterministic mode)."""
     cout, cin, kh, kw = weight.shape
     if (_FT_KERNEL and weight.is_cuda and weight.dtype == torch.bfloat16
             and weight.is_contiguous(memory_format=torch.channels_last)):
@@ -831,8 +903,9 @@ def dgrad_as_forward(dy, weight, padding):
     else:
         wt = weight.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
     pad = (kh - 1 - padding[0], kw - 1 - padding[1])
-    if conv_fwd_profitable(cout, cin, wt, (1, 1), pad) and conv_fwd_eligible(dy, wt, (1, 1), pad):
-        return conv_fwd(dy, wt, (1, 1), pad)
+    if (force_own or conv_fwd_profitable(cout, cin, wt, (1, 1), pad)) and conv_fwd_eligible(dy, wt, (1, 1), pad):
+        return conv_fwd(dy, wt, (1, 1), pad, _product="dgrad (as forward, flipped filter)")
+    _rt("dgrad (as forward, flipped filter)", wt, dy, (1, 1), "MIOpen forward kernel")
     return F.conv2d(dy, wt, None, 1, pad)
 
 
@@ -854,6 +927,7 @@ class _ConvFn(torch.autograd.Function):
                 ctx.mark_non_differentiable(part)
                 return y, part
             return conv_fwd(x, weight, stride, padding)
+        _rt("fwd", weight, x, stride, "MIOpen")
         y = F.conv2d(x, weight, None, stride, padding)
         return (y, None) if stats else y
 
@@ -882,6 +956,8 @@ class _ConvFn(torch.autograd.Function):
             wp = torch.empty((weight.shape[0], 8, weight.shape[2], weight.shape[3]), dtype=weight.dtype,
                              device=weight.device, memory_format=torch.channels_last)
             if conv_wrw_eligible(dy, xp, wp, stride, padding, min_k=0):
+                _rt("wgrad", weight, x, stride, "K6T-conv over the input padded to 8 channels")
+
                 def padded_wrw():
                     xp[:, :cin].copy_(x)
                     return conv_wrw(dy, xp, wp, stride, padding)[:, :cin].contiguous(memory_format=torch.channels_last)
@@ -893,7 +969,31 @@ class _ConvFn(torch.autograd.Function):
                 elif use_fwd:
                     dx = dgrad_as_forward(dy, weight, padding)
                 return dx, dw, None, None, None
-        mask = [ctx.needs_input_grad[0] and not use_fwd, ctx.needs_input_grad[1] and not use_tn, False]
+        strided_dx = None
+        if (_DETERMINISTIC_STRICT and ctx.needs_input_grad[0] and not use_fwd and stride[0] == stride[1] and stride[0] > 1
+                and x.is_cuda and dy.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+                and padding[0] <= weight.shape[2] - 1 and padding[1] <= weight.shape[3] - 1):
+            # strict mode: the data gradient of a strided layer (ResNet's three 3x3 / 2 layers) as the stride-1 data gradient
+            # of dY spread out with zeros between its pixels -- s^2 times the arithmetic of the library's strided kernel
+            # plus one pass to build the spread tensor, but on K13 (fixed summation order) at every batch size, where
+            # MIOpen's pick for a shape outside its tuning database may accumulate with atomics
+            sd = int(stride[0])
+            N, _, H, W = x.shape
+            kh, kw = weight.shape[2], weight.shape[3]
+            hu, wu = H + 2 * int(padding[0]) - kh + 1, W + 2 * int(padding[1]) - kw + 1
+            OH, OW = dy.shape[2], dy.shape[3]
+            up = torch.empty((N, dy.shape[1], hu, wu), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
+            up[:, :, 0:sd * (OH - 1) + 1:sd, 0:sd * (OW - 1) + 1:sd].copy_(dy)
+            wt_ok = weight.shape[0] % 32 == 0 and weight.shape[1] % 8 == 0
+            if wt_ok:
+                strided_dx = dgrad_as_forward(up, weight, padding, force_own=True)
+        mask = [ctx.needs_input_grad[0] and not use_fwd and strided_dx is None, ctx.needs_input_grad[1] and not use_tn, False]
+        if mask[0]:
+            _rt("dgrad", weight, x, stride, "MIOpen")
+        if mask[1]:
+            _rt("wgrad", weight, x, stride, "MIOpen")
+        if use_tn:
+            _rt("wgrad", weight, x, stride, "K14 direct" if conv_wrw_direct_ok(x, weight, stride, padding) else "K6T-conv")
         if mask[0] and mask[1] and _streams.ENABLED:
             # the library's data gradient on this stream, its weight gradient on the side stream
             dx, _, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, list(stride), list(padding), [1, 1], False,
@@ -909,7 +1009,9 @@ class _ConvFn(torch.autograd.Function):
                                                                 False, [0, 0], 1, mask)
                 dx, dw = (gx if mask[0] else None), (gw if mask[1] else None)
         if use_fwd:
-            dx = dgrad_as_forward(dy, weight, padding)
+            dx = dgrad_as_forward(dy, weight, padding, force_own=_DETERMINISTIC_STRICT)
+        if strided_dx is not None:
+            dx = strided_dx
         if use_tn:
             dw = _streams.run_wgrad(lambda: conv_wrw(dy, x, weight, stride, padding), weight, dy, x)
         return dx, dw, None, None, None
@@ -932,6 +1034,7 @@ class Conv2dTN(nn.Conv2d):
     def forward(self, x):
         if self._own(x)[0]:
             return _ConvFn.apply(x, self.weight, self.stride, self.padding, False)
+        _rt("fwd + bwd", self.weight, x, self.stride, "framework conv2d (MIOpen)")
         return super().forward(x)
 
     def forward_stats(self, x):

@@ -97,6 +97,10 @@ class _StemFn(torch.autograd.Function):
         lib = _lib()
         plib = poolmod._lib()
         dev = x.device
+        from . import conv as convmod
+
+        convmod._rt("fwd + bwd", w, x, (2, 2), "K15 stem (7x7 / 2 direct + BN statistics, BN + ReLU inside the pool, "
+                                              "BN backward inside the weight gradient)")
         c, part = stem_conv_fwd(x, w)
         N, C, H, W = c.shape
         M = N * H * W

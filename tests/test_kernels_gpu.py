@@ -1091,6 +1091,72 @@ def test_image_input_conv_weight_gradient_is_deterministic(dev, NB, H, W, Cout, 
     assert torch.equal(grads[0], grads[1])
 
 
+@pytest.mark.parametrize("NB,C,Co,H,k,stride,pad", [(12, 128, 128, 56, 3, 2, 1), (5, 64, 96, 35, 3, 2, 0), (3, 256, 256, 29, 3, 2, 1),
+                                                     (4, 64, 64, 30, 5, 3, 2)])
+def test_strict_mode_strided_data_gradient_on_own_kernel(dev, NB, C, Co, H, k, stride, pad, monkeypatch):
+    """DTF_DETERMINISTIC=2: the data gradient of a strided convolution is the stride-1 data gradient (K13) of dY spread
+    out with zeros -- equals conv2d's gradient for even / odd sizes, padding 0 and k // 2, stride 2 and 3; bitwise equal
+    twice; and the route trace names no library kernel for it."""
+    from distributed_tensorflow_amd.ops import conv
+
+    monkeypatch.setattr(conv, "_DETERMINISTIC_STRICT", True)
+    monkeypatch.setattr(conv, "_DETERMINISTIC", True)
+    torch.manual_seed(7)
+    m = conv.Conv2dTN(C, Co, k, stride=stride, padding=pad, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn(NB, C, H, H, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x2, w2 = x.float().requires_grad_(), m.weight.detach().float().requires_grad_()
+    y2 = F.conv2d(x2, w2, None, stride, pad)
+    dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y2.backward(dy.float())
+    outs = []
+    for _ in range(2):
+        m.weight.grad = None
+        x3 = x.clone().requires_grad_()
+        with conv.route_trace() as log:
+            m(x3).backward(dy)
+        torch.cuda.synchronize()
+        outs.append(x3.grad.clone())
+        assert x3.grad.shape == x.shape
+        assert float((x3.grad.float() - x2.grad).norm() / x2.grad.norm()) < 1e-2
+        assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
+    assert torch.equal(outs[0], outs[1])
+    dgrad = [r for r in log if r[0].startswith("dgrad")]
+    assert dgrad and all("K13" in r[3] for r in dgrad), log
+
+
+@pytest.mark.parametrize("NB,H,cin,cout", [(48, 7, 512, 2048), (3, 5, 256, 64), (48, 7, 2048, 512)])
+def test_strict_mode_1x1_products_stay_on_own_kernels(dev, NB, H, cin, cout, monkeypatch):
+    """DTF_DETERMINISTIC=2 at a pixel count K6T does not take as it is (48 x 7 x 7 = 2352 rows, not a multiple of 32; 75
+    rows, below its minimum): the weight gradient runs on K6T over zero-padded rows, forward and data gradient on the own
+    pipeline where the GEMM library holds no recorded choice -- values vs fp32, bitwise equal twice."""
+    from distributed_tensorflow_amd.ops import conv
+
+    monkeypatch.setattr(conv, "_DETERMINISTIC_STRICT", True)
+    monkeypatch.setattr(conv, "_DETERMINISTIC", True)
+    torch.manual_seed(8)
+    m = conv.Conv1x1(cin, cout).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn(NB, cin, H, H, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x2, w2 = x.float().requires_grad_(), m.weight.detach().float().requires_grad_()
+    y2 = F.conv2d(x2, w2)
+    dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y2.backward(dy.float())
+    outs = []
+    for _ in range(2):
+        m.weight.grad = None
+        x3 = x.clone().requires_grad_()
+        with conv.route_trace() as log:
+            y = m(x3)
+            y.backward(dy)
+        torch.cuda.synchronize()
+        assert float((y.detach().float() - y2.detach()).norm() / y2.detach().norm()) < 1e-2
+        assert float((x3.grad.float() - x2.grad).norm() / x2.grad.norm()) < 1e-2
+        assert float((m.weight.grad.float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
+        outs.append((y.detach().clone(), x3.grad.clone(), m.weight.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert not any("MIOpen" in r[3] for r in log), log
+
+
 @pytest.mark.parametrize("n,rows,chunk", [(1, 10, 64), (1000, 50, 64), (5000, 3, 64), (70000, 100000, 64), (300001, 7, 64),
                                           (4096, 1, 5), (2048, 2048 * 4, 64), (1025, 40, 3)])
 def test_segment_plan_kernel_matches_framework_ops(dev, n, rows, chunk):
