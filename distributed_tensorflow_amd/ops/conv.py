@@ -748,6 +748,71 @@ def conv_wrw(dy, x, weight, stride, padding):
 
 
 # ---------------------------------------------------------------------------
+# K21: weight gradient of image-input layers (Cin * KH * KW <= 32: 3x3 on RGB, 5x5 on grey-scale) as patch matrix + K6T
+# (csrc/im2col_kernels.hip).  MIOpen's kernel for these layers accumulates with atomics; this one is bitwise reproducible
+# and part of the default deterministic mode (Inception-v3's 3 -> 32 stem layer: the one gradient of the model that
+# differed run to run).
+# ---------------------------------------------------------------------------
+_IMG_WRW = os.environ.get("DTF_CONV_IMAGE_WRW", "1") != "0"
+_img_declared = False
+
+
+def _img_lib():
+    global _img_declared
+    import ctypes
+
+    from . import hip
+
+    lib = hip.lib()
+    if not _img_declared and hasattr(lib, "dtf_im2col_small"):
+        P, I, L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        hip.declare("dtf_im2col_small_ok", [L, I, I, I, I, I, I, I, I], I)
+        hip.declare("dtf_im2col_small", [P, P, L, I, I, I, I, I, I, I, I, L, P])
+        _img_declared = True
+    return lib
+
+
+def image_wrw_eligible(dy, x, weight, stride, padding):
+    cout, cin, kh, kw = weight.shape
+    if not (_IMG_WRW and _CONV_WRW and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and cin == x.shape[1] and cin * kh * kw <= 32 and cout % 8 == 0
+            and stride[0] == stride[1] and x.is_contiguous(memory_format=torch.channels_last)
+            and dy.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
+            and dy.shape[0] * dy.shape[2] * dy.shape[3] < (1 << 31) - 1024):
+        return False
+    lib = _img_lib()
+    return hasattr(lib, "dtf_im2col_small") and lib.dtf_im2col_small_ok(x.shape[0], x.shape[2], x.shape[3], cin, kh, kw,
+                                                                         int(stride[0]), int(padding[0]), int(padding[1])) == 0
+
+
+def image_wrw(dy, x, weight, stride, padding):
+    """``dW`` of ``conv2d(x, weight, stride, padding)`` for an input with a few channels (``Cin * KH * KW <= 32``): the patch
+    matrix ``[pixels, 32]`` written once by K21, then ``dY^T . P`` on K6T.  Channels-last ``[Cout, Cin, KH, KW]`` result."""
+    from . import hip
+    from .linear import gemm_tn
+
+    lib = _img_lib()
+    cout, cin, kh, kw = weight.shape
+    N, _, H, W = x.shape
+    OH, OW = dy.shape[2], dy.shape[3]
+    M = N * OH * OW
+    Mp = max(1024, (M + 31) // 32 * 32)         # K6T: whole 32-row reduction tiles
+    P = torch.empty(Mp, 32, dtype=torch.bfloat16, device=x.device)
+    rc = lib.dtf_im2col_small(hip.ptr(x), hip.ptr(P), N, H, W, cin, kh, kw, int(stride[0]), int(padding[0]), int(padding[1]), Mp,
+                              hip.stream())
+    hip.check(rc, "dtf_im2col_small")
+    dy2 = _rows(dy)
+    if Mp != M:
+        dyp = torch.zeros(Mp, cout, dtype=dy.dtype, device=dy.device)
+        dyp[:M].copy_(dy2)
+        dy2 = dyp
+    g = gemm_tn(dy2, P)                          # [Cout, 32]: columns (r * KW + s) * Cin + c, the rest zero
+    # contiguous(): the 27 of 32 columns as a dense [Cout, KH, KW, Cin] tensor -- a strided view here would make autograd
+    # clone the gradient into the parameter's layout on ITS stream (see streams._in_param_layout)
+    return g[:, :cin * kh * kw].contiguous().view(cout, kh, kw, cin).permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------
 # K13: forward convolution as an implicit GEMM on the K6 LDS-DMA pipeline (csrc/conv_kernels.hip)
 # ---------------------------------------------------------------------------
 _fwd_declared = False
@@ -943,7 +1008,9 @@ class _ConvFn(torch.autograd.Function):
         use_tn = (ctx.needs_input_grad[1] and _CONV_WRW and conv_wrw_profitable(weight, x, stride, padding)
                   and conv_wrw_eligible(dy, x, weight, stride, padding))
         use_fwd = ctx.needs_input_grad[0] and _dgrad_as_fwd_ok(x, weight, stride, padding)
-        if (_DETERMINISTIC_STRICT and ctx.needs_input_grad[1] and not use_tn and _CONV_WRW and weight.shape[1] < 8
+        use_img = (_DETERMINISTIC and ctx.needs_input_grad[1] and not use_tn and weight.shape[1] < 8
+                   and image_wrw_eligible(dy, x, weight, stride, padding))
+        if (_DETERMINISTIC_STRICT and ctx.needs_input_grad[1] and not use_tn and not use_img and _CONV_WRW and weight.shape[1] < 8
                 and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
             # an image-input layer (3 channels; Inception-v3's 3x3 / 2 stem): no own kernel takes fewer than 8 input
             # channels and MIOpen's weight gradient accumulates with atomics -- the one tensor of Inception-v3 that
@@ -987,7 +1054,10 @@ class _ConvFn(torch.autograd.Function):
             wt_ok = weight.shape[0] % 32 == 0 and weight.shape[1] % 8 == 0
             if wt_ok:
                 strided_dx = dgrad_as_forward(up, weight, padding, force_own=True)
-        mask = [ctx.needs_input_grad[0] and not use_fwd and strided_dx is None, ctx.needs_input_grad[1] and not use_tn, False]
+        mask = [ctx.needs_input_grad[0] and not use_fwd and strided_dx is None,
+                ctx.needs_input_grad[1] and not use_tn and not use_img, False]
+        if use_img:
+            _rt("wgrad", weight, x, stride, "K21 patch matrix + K6T")
         if mask[0]:
             _rt("dgrad", weight, x, stride, "MIOpen")
         if mask[1]:
@@ -1014,6 +1084,8 @@ class _ConvFn(torch.autograd.Function):
             dx = strided_dx
         if use_tn:
             dw = _streams.run_wgrad(lambda: conv_wrw(dy, x, weight, stride, padding), weight, dy, x)
+        if use_img:
+            dw = _streams.run_wgrad(lambda: image_wrw(dy, x, weight, stride, padding), weight, dy, x)
         return dx, dw, None, None, None
 
 

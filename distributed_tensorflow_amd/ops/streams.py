@@ -41,6 +41,18 @@ def join_into(stream, device):
         stream.wait_stream(s)
 
 
+def _in_param_layout(out, weight):
+    """AccumulateGrad keeps a gradient as it is only when its strides are the parameter's; otherwise it stores a CLONE --
+    made on the stream backward runs on, which has not waited for this one: the clone would read memory the weight-gradient
+    kernel has not written yet (found with K21, whose result was a strided view: the first step's gradient of
+    Inception-v3's stem layer came out as zeros, later steps "worked" because the allocator handed back the block that
+    still held the previous step's values).  So the copy into the parameter's layout, where one is needed, is made
+    here, on the side stream."""
+    if (isinstance(out, torch.Tensor) and weight is not None and out.shape == weight.shape and out.stride() != weight.stride()):
+        return torch.empty_like(weight, dtype=out.dtype).copy_(out)
+    return out
+
+
 def run_wgrad(fn, weight, *inputs):
     """``fn()`` -- the weight gradient of ``weight`` -- on the weight-gradient stream, ordered after the current stream;
     returns its result.
@@ -92,7 +104,7 @@ def run_wgrad(fn, weight, *inputs):
             _join_queued.discard(key)
             torch.cuda.set_stream(side)
             try:
-                out = fn()
+                out = _in_param_layout(fn(), weight)
             finally:
                 torch.cuda.set_stream(cur)
             cur.wait_stream(side)
@@ -102,7 +114,7 @@ def run_wgrad(fn, weight, *inputs):
         _checks.append((tuple(i.clone() for i in inputs), inputs, tuple(i.shape for i in inputs)))
     torch.cuda.set_stream(side)
     try:
-        out = fn()
+        out = _in_param_layout(fn(), weight)
     finally:
         torch.cuda.set_stream(cur)
     _held.setdefault(key, []).append(inputs)

@@ -1091,6 +1091,83 @@ def test_image_input_conv_weight_gradient_is_deterministic(dev, NB, H, W, Cout, 
     assert torch.equal(grads[0], grads[1])
 
 
+def test_side_stream_gradient_in_a_foreign_layout_is_copied_on_the_side_stream(dev):
+    """A weight gradient whose strides are not the parameter's makes autograd store a CLONE -- made on the stream backward
+    runs on, which has not waited for the weight-gradient stream (the regression this pins: K21 returned a strided view
+    and the first step's gradient of Inception-v3's stem layer came out as zeros).  ``run_wgrad`` therefore copies into the
+    parameter's layout itself, on the side stream.  Checked as a property that does not depend on timing: what
+    ``run_wgrad`` returns has the parameter's strides, and autograd KEEPS that very tensor as ``.grad`` (same storage), so
+    no copy was made behind the side stream's back; values equal the reference."""
+    from distributed_tensorflow_amd.ops import streams
+
+    assert streams.ENABLED
+    returned = []
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, w = ctx.saved_tensors
+
+            def wgrad():
+                full = torch.full((w.shape[0], 32), 7.0, device=dy.device)
+                full[:, :w.shape[1]] = dy.t() @ x
+                return full[:, :w.shape[1]]                     # strides (32, 1): not the parameter's (27, 1)
+
+            out = streams.run_wgrad(wgrad, w, dy, x)
+            returned.append((out.data_ptr(), out.stride()))
+            return None, out
+
+    torch.manual_seed(0)
+    x = torch.randn(64, 27, device=dev)
+    w = torch.randn(8, 27, device=dev, requires_grad=True)
+    dy = torch.randn(64, 8, device=dev)
+    for _ in range(2):
+        w.grad = None
+        Fn.apply(x, w).backward(dy)
+        torch.cuda.synchronize()
+        ptr, strides = returned[-1]
+        assert strides == w.stride()
+        assert w.grad.data_ptr() == ptr, "autograd cloned the gradient: the copy ran on the compute stream"
+        torch.testing.assert_close(w.grad, dy.t() @ x, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("NB,Cin,H,W,Cout,k,stride,pad", [(32, 3, 149, 149, 32, 3, 2, 0), (5, 3, 75, 61, 32, 3, 2, 0), (8, 3, 33, 33, 64, 3, 1, 1),
+                                                          (7, 1, 28, 28, 16, 5, 1, 2), (3, 2, 40, 37, 24, 4, 2, 1), (1, 3, 9, 9, 8, 3, 1, 0)])
+def test_image_input_weight_gradient_k21(dev, NB, Cin, H, W, Cout, k, stride, pad):
+    """K21 (patch matrix of a few-channel input + K6T), the DEFAULT route of image-input layers: equals conv2d's weight
+    gradient (pixel counts that are / are not whole 32-row tiles, below K6T's minimum, padding, Cin 1 / 2 / 3, even kernel
+    size), is bitwise equal twice, and the module names it in the route trace."""
+    from distributed_tensorflow_amd.ops import conv
+
+    assert conv._DETERMINISTIC and not conv._DETERMINISTIC_STRICT
+    torch.manual_seed(11)
+    m = conv.Conv2dTN(Cin, Cout, k, stride=stride, padding=pad, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn(NB, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x2, w2 = x.float(), m.weight.detach().float().requires_grad_()
+    y2 = F.conv2d(x2, w2, None, stride, pad)
+    dy = torch.randn_like(y2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y2.backward(dy.float())
+    assert conv.image_wrw_eligible(dy, x, m.weight, (stride, stride), (pad, pad))
+    direct = conv.image_wrw(dy, x, m.weight, (stride, stride), (pad, pad))
+    assert direct.shape == m.weight.shape
+    assert float((direct.float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
+    grads = []
+    for _ in range(2):
+        m.weight.grad = None
+        with conv.route_trace() as log:
+            m(x).backward(dy)
+        torch.cuda.synchronize()
+        grads.append(m.weight.grad.clone())
+    assert any(r[0] == "wgrad" and "K21" in r[3] for r in log), log
+    assert float((grads[0].float() - w2.grad).norm() / w2.grad.norm()) < 1e-2
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], direct)
+
+
 @pytest.mark.parametrize("NB,C,Co,H,k,stride,pad", [(12, 128, 128, 56, 3, 2, 1), (5, 64, 96, 35, 3, 2, 0), (3, 256, 256, 29, 3, 2, 1),
                                                      (4, 64, 64, 30, 5, 3, 2)])
 def test_strict_mode_strided_data_gradient_on_own_kernel(dev, NB, C, Co, H, k, stride, pad, monkeypatch):
