@@ -754,6 +754,7 @@ def conv_wrw(dy, x, weight, stride, padding):
 # differed run to run).
 # ---------------------------------------------------------------------------
 _IMG_WRW = os.environ.get("DTF_CONV_IMAGE_WRW", "1") != "0"
+_IMG_WRW_GROUP = int(os.environ.get("DTF_CONV_IMAGE_WRW_GROUP", "8"))       # A/B switch: 1 = plain [M, 32] operands
 _img_declared = False
 
 
@@ -778,7 +779,7 @@ def image_wrw_eligible(dy, x, weight, stride, padding):
             and weight.dtype == torch.bfloat16 and cin == x.shape[1] and cin * kh * kw <= 32 and cout % 8 == 0
             and stride[0] == stride[1] and x.is_contiguous(memory_format=torch.channels_last)
             and dy.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0 and dy.data_ptr() % 16 == 0
-            and dy.shape[0] * dy.shape[2] * dy.shape[3] < (1 << 31) - 1024):
+            and dy.shape[0] * dy.shape[2] * dy.shape[3] < (1 << 31) - (1 << 26)):
         return False
     lib = _img_lib()
     return hasattr(lib, "dtf_im2col_small") and lib.dtf_im2col_small_ok(x.shape[0], x.shape[2], x.shape[3], cin, kh, kw,
@@ -806,7 +807,17 @@ def image_wrw(dy, x, weight, stride, padding):
         dyp = torch.zeros(Mp, cout, dtype=dy.dtype, device=dy.device)
         dyp[:M].copy_(dy2)
         dy2 = dyp
-    g = gemm_tn(dy2, P)                          # [Cout, 32]: columns (r * KW + s) * Cin + c, the rest zero
+    if _IMG_WRW_GROUP > 1 and Mp == M and M % (32 * _IMG_WRW_GROUP) == 0 and cout * _IMG_WRW_GROUP <= 512:
+        # K6T streams two 32-column operands at half its rate (a 256-wide K tile of which 32 columns are real: 277 us for
+        # the 728 MB of Inception-v3's stem layer).  Rows taken G at a time -- dY as [M / G, G * Cout], P as [M / G, G * 32],
+        # both free views -- give it full-width tiles; the wanted product is the sum of the G diagonal blocks of the
+        # [G * Cout, G * 32] result (the off-diagonal blocks pair different pixels: G times the arithmetic, which the
+        # matrix cores do not notice next to the HBM stream).  fp32 blocks, summed in a fixed order.
+        G = _IMG_WRW_GROUP
+        big = gemm_tn(dy2.view(M // G, G * cout), P.view(M // G, G * 32), out_dtype=torch.float32)
+        g = torch.diagonal(big.view(G, cout, G, 32), dim1=0, dim2=2).sum(-1).to(torch.bfloat16)      # [Cout, 32]
+    else:
+        g = gemm_tn(dy2, P)                      # [Cout, 32]: columns (r * KW + s) * Cin + c, the rest zero
     # contiguous(): the 27 of 32 columns as a dense [Cout, KH, KW, Cin] tensor -- a strided view here would make autograd
     # clone the gradient into the parameter's layout on ITS stream (see streams._in_param_layout)
     return g[:, :cin * kh * kw].contiguous().view(cout, kh, kw, cin).permute(0, 3, 1, 2)

@@ -1137,11 +1137,13 @@ def test_side_stream_gradient_in_a_foreign_layout_is_copied_on_the_side_stream(d
 
 
 @pytest.mark.parametrize("NB,Cin,H,W,Cout,k,stride,pad", [(32, 3, 149, 149, 32, 3, 2, 0), (5, 3, 75, 61, 32, 3, 2, 0), (8, 3, 33, 33, 64, 3, 1, 1),
-                                                          (7, 1, 28, 28, 16, 5, 1, 2), (3, 2, 40, 37, 24, 4, 2, 1), (1, 3, 9, 9, 8, 3, 1, 0)])
+                                                          (7, 1, 28, 28, 16, 5, 1, 2), (3, 2, 40, 37, 24, 4, 2, 1), (1, 3, 9, 9, 8, 3, 1, 0),
+                                                          (64, 3, 21, 21, 32, 3, 2, 0), (256, 3, 9, 9, 64, 3, 1, 1)])
 def test_image_input_weight_gradient_k21(dev, NB, Cin, H, W, Cout, k, stride, pad):
     """K21 (patch matrix of a few-channel input + K6T), the DEFAULT route of image-input layers: equals conv2d's weight
     gradient (pixel counts that are / are not whole 32-row tiles, below K6T's minimum, padding, Cin 1 / 2 / 3, even kernel
-    size), is bitwise equal twice, and the module names it in the route trace."""
+    size; the last two cases have a pixel count that is a multiple of 256 and take the grouped-rows form of the product),
+    is bitwise equal twice, and the module names it in the route trace."""
     from distributed_tensorflow_amd.ops import conv
 
     assert conv._DETERMINISTIC and not conv._DETERMINISTIC_STRICT
