@@ -41,6 +41,9 @@ def join_into(stream, device):
         stream.wait_stream(s)
 
 
+layout_copies = 0        # how often a weight gradient came back in a foreign layout (diagnostics / tests)
+
+
 def _in_param_layout(out, weight):
     """AccumulateGrad keeps a gradient as it is only when its strides are the parameter's; otherwise it stores a CLONE --
     made on the stream backward runs on, which has not waited for this one: the clone would read memory the weight-gradient
@@ -49,6 +52,8 @@ def _in_param_layout(out, weight):
     still held the previous step's values).  So the copy into the parameter's layout, where one is needed, is made
     here, on the side stream."""
     if (isinstance(out, torch.Tensor) and weight is not None and out.shape == weight.shape and out.stride() != weight.stride()):
+        global layout_copies
+        layout_copies += 1
         return torch.empty_like(weight, dtype=out.dtype).copy_(out)
     return out
 

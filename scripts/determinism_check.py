@@ -34,4 +34,6 @@ for it in range(6):
         mags = ["%s %.2e" % (n, float((g[n].float() - ref[n].float()).norm() / ref[n].float().norm())) for n in diff[:8]]
         print("iteration %d vs %d: %d tensors differ (loss %.7f vs %.7f): %s" % (it, it - 1, len(diff), float(loss), ref_loss, "; ".join(mags)), flush=True)
     ref, ref_loss = g, float(loss)
-print("loss %.6f  non-reproducible iterations: %d" % (float(loss), bad))
+from distributed_tensorflow_amd.ops import streams
+print("loss %.6f  non-reproducible iterations: %d  (weight gradients copied into the parameter layout on the side stream: %d per pass)"
+      % (float(loss), bad, streams.layout_copies // 6))
