@@ -86,3 +86,26 @@ def test_subsample_fork_gradient():
     out2.backward()
     torch.testing.assert_close(out1, out2)
     torch.testing.assert_close(x1.grad, x2.grad)
+
+
+def test_weight_gradient_is_brought_into_the_parameter_layout():
+    """ops/streams._in_param_layout (the copy autograd would otherwise make on the wrong stream, see its docstring): a
+    gradient with the parameter's strides passes through untouched, a strided view comes back dense in the parameter's
+    layout (channels-last included) with the same values, and the diagnostic counter moves."""
+    import torch
+
+    from distributed_tensorflow_amd.ops import streams
+
+    w = torch.randn(8, 3, 3, 3).contiguous(memory_format=torch.channels_last)
+    same = torch.randn(8, 3, 3, 3).contiguous(memory_format=torch.channels_last)
+    assert streams._in_param_layout(same, w) is same
+    before = streams.layout_copies
+    wide = torch.randn(8, 32)
+    view = wide[:, :27].reshape(8, 3, 3, 3).permute(0, 3, 1, 2)          # strides (32, 1, 9, 3): K21's first version
+    assert view.stride() != w.stride()
+    out = streams._in_param_layout(view, w)
+    assert out.stride() == w.stride() and torch.equal(out, view) and out.data_ptr() != view.data_ptr()
+    assert streams.layout_copies == before + 1
+    assert streams._in_param_layout(None, w) is None
+    other_shape = torch.randn(4, 27)
+    assert streams._in_param_layout(other_shape, w) is other_shape
