@@ -358,3 +358,36 @@ def test_bench_ends_at_the_same_loss_through_every_data_plane_path():
                              ("async", {"DTF_FORCE_COMM": "1"}, ["--update-mode", "async"])]:
         got = run(env, *extra)
         assert got == ref, "%s: %r vs %r" % (name, got, ref)
+
+
+@pytest.mark.parametrize("model,batch,steps", [("resnet50", 64, 8), ("bert", 16, 6), ("wide_deep", 65536, 6)])
+def test_pipelined_step_equals_serialised_execution_bit_for_bit(dev, model, batch, steps):
+    """The pipelined step (weight-gradient side stream, comm stream through a live 1-rank RCCL group, per-bucket pull
+    prefetch, gradient hooks, no host synchronisation) against a fully serialised execution of the same training
+    (AMD_SERIALIZE_KERNEL=3, synchronise after backward and after the PS step, no side stream, no prefetch), with a
+    DIFFERENT batch and learning rate every step -- bench.py's single fixed batch would hide a consumer that reads a
+    buffer one step early.  SHA-256 over every parameter, BatchNorm buffer, fp32 master and optimizer slot must be equal
+    (scripts/serial_vs_pipelined.py, own processes)."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "scripts", "serial_vs_pipelined.py")
+    base = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    hashes = []
+    for extra in ({}, {"DTF_SERIAL": "1", "DTF_WGRAD_STREAM": "0", "DTF_PULL_PREFETCH": "0", "AMD_SERIALIZE_KERNEL": "3"}):
+        env = dict(base)
+        env.update(extra)
+        env["MASTER_PORT"] = str(_free_port())
+        r = subprocess.run([sys.executable, script, model, str(batch), str(steps)], capture_output=True, text=True, timeout=600,
+                           env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        m = re.search(r"state hash over (\d+) tensors: ([0-9a-f]{64})", r.stdout)
+        assert m, r.stdout[-1500:]
+        losses = re.search(r"losses (.*)", r.stdout).group(1)
+        hashes.append((m.group(2), losses))
+    assert hashes[0][1] == hashes[1][1], hashes
+    assert hashes[0][0] == hashes[1][0], "pipelined and serialised runs end in different states"
