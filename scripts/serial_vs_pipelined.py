@@ -27,15 +27,22 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 serial = os.environ.get("DTF_SERIAL", "0") == "1"
 torch.manual_seed(1234)
-comm = Comm.from_env(force=bool(int(os.environ.get("DTF_FORCE_COMM", "1"))))
+comm = Comm.from_env(force=bool(int(os.environ.get("DTF_FORCE_COMM", "1"))), backend=os.environ.get("DTF_COMM_BACKEND") or None)
 dev = comm.device
 mod = get_model_module(name)
 kw = dict(comm=comm, device=dev) if getattr(mod, "NEEDS_COMM", False) else {}
 m = mod.build(**kw)
 m = (mod.prepare(m, dev) if hasattr(mod, "prepare") else m.to(dev)).train()
 opt = mod.default_optimizer()
-ps = ShardedPS(list(m.named_parameters()), comm, opt, bucket_mb=32.0)
-if hasattr(ps, "attach"):
+mode = os.environ.get("DTF_UPDATE_MODE", "sync")               # sync | stale | async
+if mode == "async":
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncPS
+
+    ps = AsyncPS(list(m.named_parameters()), comm, opt, bucket_mb=32.0)
+else:
+    ps = ShardedPS(list(m.named_parameters()), comm, opt, bucket_mb=32.0, update_mode=mode,
+                   push=os.environ.get("DTF_PUSH", "reduce_scatter"), staleness=int(os.environ.get("DTF_STALENESS", "1")))
+if mode == "sync" and hasattr(ps, "attach"):
     ps.attach(m)
 bkw = dict(model=m) if getattr(mod, "NEEDS_COMM", False) else {}
 batches = [mod.synthetic_batch(B, device=dev, seed=500 + i, **bkw) for i in range(5)]       # a different batch every step
@@ -61,8 +68,8 @@ for k, v in sorted(m.state_dict().items()):
 for t in (getattr(ps, "master", None), getattr(ps, "slot_m", None), getattr(ps, "slot_v", None)):
     if isinstance(t, torch.Tensor):
         h.update(t.detach().cpu().reshape(-1).contiguous().view(torch.uint8).numpy().tobytes())
-print("%s batch %d steps %d serial=%d side_stream=%s prefetch=%s: losses %s" % (
-    name, B, steps, serial, os.environ.get("DTF_WGRAD_STREAM", "1"), os.environ.get("DTF_PULL_PREFETCH", "1"),
+print("%s batch %d steps %d mode=%s push=%s comm=%s serial=%d side_stream=%s prefetch=%s: losses %s" % (
+    name, B, steps, mode, os.environ.get("DTF_PUSH", "reduce_scatter"), os.environ.get("DTF_COMM_BACKEND", "nccl"), serial, os.environ.get("DTF_WGRAD_STREAM", "1"), os.environ.get("DTF_PULL_PREFETCH", "1"),
     " ".join("%.4f" % float(l) for l in losses)))
 print("state hash over %d tensors: %s" % (n, h.hexdigest()))
 comm.close()
