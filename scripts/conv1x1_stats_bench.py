@@ -14,6 +14,10 @@ hip.lib()
 dev = torch.device("cuda:0")
 SHAPES = [(256, 56, 64, 256, 4), (256, 28, 128, 512, 4), (256, 28, 256, 512, 0), (256, 14, 256, 1024, 6), (256, 7, 512, 2048, 3),
           (256, 35, 192, 64, 0), (256, 17, 768, 192, 0), (256, 8, 1280, 320, 0)]
+if os.environ.get("DTF_BENCH_ALL_RESNET") == "1":       # every 1x1 forward product of ResNet-50 at batch 256 with Cout >= 128
+    SHAPES = [(256, 56, 256, 128, 1), (256, 28, 128, 512, 4), (256, 28, 512, 128, 3), (256, 28, 256, 512, 1), (256, 28, 512, 256, 1),
+              (256, 14, 256, 1024, 6), (256, 14, 1024, 256, 5), (256, 14, 512, 1024, 1), (256, 14, 1024, 512, 1),
+              (256, 7, 512, 2048, 3), (256, 7, 2048, 512, 2), (256, 7, 1024, 2048, 1)]
 
 
 def timeit(fn, n=20):
