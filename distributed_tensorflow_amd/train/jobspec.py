@@ -43,10 +43,12 @@ class TrainOptions:
     graph: bool = False             # capture the whole training step in one hipGraph after 3 eager steps
     gemm_tuning: str = "auto"       # shipped per-shape GEMM choices: on | off | auto (on from 10 000 steps: reading them
                                     # costs 1-1.5 s before the first step and returns 1-1.5 % per step)
+    input: str = "auto"             # auto: the job's `data` directory if it holds a dataset (train/data.py) | synthetic
+    synthetic_batches: int = 1      # synthetic input: this many different batches, served round-robin
     extra: dict = field(default_factory=dict)
 
 
-_INT = {"steps", "batch", "ckpt_every", "seed", "log_every", "staleness"}
+_INT = {"steps", "batch", "ckpt_every", "seed", "log_every", "staleness", "synthetic_batches"}
 _FLOAT = {"bucket_mb", "lr"}
 _BOOL = {"resume", "graph"}
 

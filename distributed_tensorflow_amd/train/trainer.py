@@ -115,25 +115,60 @@ def restore_checkpoint(model, ps, export, tf_names):
 
 
 def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=None, on_step=None,
-               items_per_step=None, start_step=0, graph=False):
+               items_per_step=None, start_step=0, graph=False, batches=None):
     """Runs ``steps`` PS steps; returns (last_loss, seconds, steps_done).  ``graph=True``: after three eager steps
     the whole step (forward, backward, hook-launched PS pipeline incl. its collectives) is captured in one hipGraph
-    and replayed -- the ~600 launches of a step then cost the host one call (GPU only)."""
+    and replayed -- the ~600 launches of a step then cost the host one call (GPU only).
+
+    ``batches``: an iterator of device batches (``train/data.py``: the job's ``data`` directory through the prefetcher, or
+    several synthetic batches); ``batch`` is then the first of them.  With ``graph=True`` every new batch is copied INTO
+    the tensors of ``batch`` (a replayed graph reads fixed addresses); eagerly the step just takes the new tensors."""
     dev = ps.device
     t0 = time.time()
     last = None
     loss = None
+    cur = {"b": batch}
+    static_input = bool(graph) and dev.type == "cuda"
 
     def eager():
-        out = mod.loss_fn(model, batch)
+        out = mod.loss_fn(model, cur["b"])
         out.backward()
         ps.step()
         return out
 
+    def next_batch(first):
+        if batches is None or first:          # `batch` IS the first element of `batches`
+            return
+        nb = next(batches)
+        if static_input:
+            with torch.no_grad():
+                for d, s in zip(cur["b"], nb):
+                    if isinstance(d, torch.Tensor):
+                        d.copy_(s)
+        else:
+            cur["b"] = nb
+
     replay, static_loss = None, None
+    # the eager steps before a capture run on a side stream (the protocol torch.cuda.graph documents and bench.py follows):
+    # captured after warm-up steps on the DEFAULT stream, hipStreamEndCapture crashed the process on ROCm 7.2
+    warm = None
+    if graph and dev.type == "cuda" and steps > 3:
+        warm = torch.cuda.Stream(dev)
+        warm.wait_stream(torch.cuda.current_stream(dev))
     for it in range(start_step, start_step + steps):
         _inject(fault, worker, it + 1)
+        warming = warm is not None and replay is None and graph and it - start_step < 3
+        if warming:
+            with torch.cuda.stream(warm):
+                next_batch(it == start_step)
+                loss = eager()
+            if on_step is not None:
+                on_step(it + 1, loss)
+            continue
+        next_batch(it == start_step)
         if graph and dev.type == "cuda" and replay is None and it - start_step == 3:
+            if warm is not None:
+                torch.cuda.current_stream(dev).wait_stream(warm)
             torch.cuda.synchronize(dev)
             time.sleep(0.5)             # the RCCL watchdog retires the earlier collectives (no event queries mid-capture)
             if hasattr(ps, "disable_prefetch"):
@@ -334,8 +369,31 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
     bkw = {k: int(v) for k, v in opts.extra.items() if k in ("seq_len", "image_size")}
     if getattr(mod, "NEEDS_COMM", False):
         bkw["model"] = model
-    batch = mod.synthetic_batch(opts.batch, device=device, seed=opts.seed + 1 + task_index, **bkw)
-    mark("synthetic batch on the device")
+    batches = None
+    dataset = None
+    if opts.input != "synthetic":
+        from . import data as data_mod
+
+        dataset = data_mod.open_dataset(data_dir)
+    if dataset is not None:
+        # the job's `data` directory (reference: argv[6] of the training script, handlers/train_handler.py:82-83)
+        stream = data_mod.BatchStream(dataset, opts.batch, worker=task_index, num_workers=num_workers, seed=opts.seed,
+                                      start_step=start_step)
+        batches = data_mod.Prefetcher(stream, data_mod.transform_for(mod, dataset, device), device)
+        batch = next(batches)
+        print("[worker %d] input: %d samples from %s (%s), %d steps per epoch" % (
+            task_index, len(dataset), dataset.source, dataset.kind, stream.per_epoch), flush=True)
+        mark("first batch of the dataset on the device")
+    else:
+        batch = mod.synthetic_batch(opts.batch, device=device, seed=opts.seed + 1 + task_index, **bkw)
+        if opts.synthetic_batches > 1:
+            from . import data as data_mod
+
+            batches = data_mod.Cycle([batch] + [
+                mod.synthetic_batch(opts.batch, device=device, seed=opts.seed + 1 + task_index + 7919 * k, **bkw)
+                for k in range(1, opts.synthetic_batches)])
+            batch = next(batches)
+        mark("synthetic batch on the device")
     fault = _parse_fault(opts.fault)
     first = {"done": False}
 
@@ -368,9 +426,13 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
 
     remaining = max(0, opts.steps - start_step)
     items = opts.batch * num_workers
-    last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
-                               fault=fault, on_step=on_step, items_per_step=items, start_step=start_step,
-                               graph=opts.graph and placement != "dedicated" and not one_sided)
+    try:
+        last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
+                                   fault=fault, on_step=on_step, items_per_step=items, start_step=start_step,
+                                   graph=opts.graph and placement != "dedicated" and not one_sided, batches=batches)
+    finally:
+        if batches is not None:
+            batches.close()
     rate = n * items / max(secs, 1e-9)
     print("[worker %d] done: %d steps in %.2f s, %.1f items/s, final loss %s" % (
         task_index, n, secs, rate, last), flush=True)

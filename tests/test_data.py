@@ -1,0 +1,264 @@
+"""The input pipeline of the built-in workloads (train/data.py): the job's ``data`` field, which the reference hands to the
+training script as argv[6] (/root/reference/handlers/train_handler.py:82-83; its sample job reads MNIST IDX files there)."""
+import json
+import os
+import time
+import urllib.request
+
+import numpy as np
+import pytest
+import torch
+
+from distributed_tensorflow_amd.train import data as D
+
+
+def _digits(n, seed=0):
+    """Digits with the structure of models/mnist_mlp.synthetic_batch (class k lights up band k) as uint8 images."""
+    rng = np.random.default_rng(seed)
+    y = rng.integers(0, 10, n).astype(np.uint8)
+    x = (rng.random((n, 784)) * 80).astype(np.uint8)
+    band = 784 // 10
+    for k in range(10):
+        x[y == k, k * band:(k + 1) * band] += 150
+    return x.reshape(n, 28, 28), y
+
+
+def test_idx_round_trip_plain_and_gzipped(tmp_path):
+    x, y = _digits(50)
+    for name, a in (("a-idx3-ubyte", x), ("b-idx1-ubyte.gz", y)):
+        p = str(tmp_path / name)
+        D.write_idx(p, a)
+        b = D.read_idx(p)
+        assert b.dtype == np.uint8 and b.shape == a.shape and (b == a).all()
+    (tmp_path / "junk").write_bytes(b"\x01\x02\x03\x04rest")
+    with pytest.raises(ValueError):
+        D.read_idx(str(tmp_path / "junk"))
+    D.write_idx(str(tmp_path / "short"), x)
+    raw = (tmp_path / "short").read_bytes()
+    (tmp_path / "short").write_bytes(raw[:len(raw) // 2])
+    with pytest.raises(ValueError):
+        D.read_idx(str(tmp_path / "short"))
+
+
+def test_open_dataset_recognises_the_three_layouts(tmp_path):
+    assert D.open_dataset("") is None and D.open_dataset(str(tmp_path / "missing")) is None
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    assert D.open_dataset(str(empty)) is None             # e.g. the shipped post-data's /data/imagenet-synthetic
+    x, y = _digits(40)
+    m = tmp_path / "mnist"
+    m.mkdir()
+    D.write_idx(str(m / "train-images-idx3-ubyte.gz"), x)
+    D.write_idx(str(m / "train-labels-idx1-ubyte"), y)
+    ds = D.open_dataset(str(m))
+    assert ds.kind == "mnist" and len(ds) == 40 and (ds.fields[0] == x).all()
+    n = tmp_path / "npy"
+    n.mkdir()
+    np.save(n / "images.npy", np.zeros((12, 8, 8, 3), np.uint8))
+    np.save(n / "labels.npy", np.arange(12))
+    ds = D.open_dataset(str(n))
+    assert ds.kind == "images" and len(ds) == 12 and isinstance(ds.fields[0], np.memmap)
+    g = tmp_path / "generic"
+    g.mkdir()
+    np.save(g / "ids.npy", np.arange(30).reshape(10, 3))
+    np.save(g / "dense.npy", np.ones((10, 4), np.float32))
+    np.save(g / "y.npy", np.zeros(10, np.float32))
+    (g / "manifest.json").write_text(json.dumps({"fields": ["ids.npy", "../generic/dense.npy", "y.npy"]}))
+    ds = D.open_dataset(str(g))
+    assert ds.kind == "generic" and [a.shape[1:] for a in ds.fields] == [(3,), (4,), ()]
+    np.save(g / "y.npy", np.zeros(9, np.float32))
+    with pytest.raises(ValueError):
+        D.open_dataset(str(g))
+
+
+def test_batch_stream_shards_like_between_graph_replication():
+    """W workers draw the same permutation: their batches of one step are disjoint and together the global batch; an epoch
+    shows every sample at most once; the next epoch is shuffled differently; the same seed repeats; a resumed stream
+    continues with the batch the original one would have produced next."""
+    N, W, B = 103, 4, 8
+    ds = D.ArrayDataset([np.arange(N), np.arange(N) * 10])
+    streams = [D.BatchStream(ds, B, worker=w, num_workers=W, seed=5) for w in range(W)]
+    assert streams[0].per_epoch == N // (W * B) == 3
+    seen = []
+    for step in range(3):
+        parts = [next(s) for s in streams]
+        ids = np.concatenate([p[0] for p in parts])
+        assert len(set(ids.tolist())) == W * B
+        assert all((p[1] == p[0] * 10).all() for p in parts)            # fields stay aligned
+        seen += ids.tolist()
+    assert len(set(seen)) == len(seen) == 3 * W * B                      # one epoch: no sample twice
+    epoch2 = np.concatenate([next(s)[0] for s in streams])
+    again = D.BatchStream(ds, B, worker=0, num_workers=W, seed=5)
+    first = next(again)[0]
+    assert set(first.tolist()) == set(streams[0].indices(0).tolist())
+    assert set(epoch2.tolist()) != set(seen[:W * B])
+    resumed = D.BatchStream(ds, B, worker=2, num_workers=W, seed=5, start_step=4)
+    assert (next(resumed)[0] == np.sort(streams[2].indices(4))).all()
+    with pytest.raises(ValueError):
+        D.BatchStream(ds, 64, worker=0, num_workers=2)
+
+
+def test_prefetcher_delivers_the_stream_in_order_and_reports_errors():
+    ds = D.ArrayDataset([np.arange(64, dtype=np.float32).reshape(64, 1), np.arange(64)])
+    direct = D.BatchStream(ds, 8, seed=1)
+    want = [next(direct) for _ in range(10)]
+    pf = D.Prefetcher(D.BatchStream(ds, 8, seed=1), lambda ts: tuple(ts), "cpu", depth=3)
+    got = [next(pf) for _ in range(10)]
+    pf.close()
+    for w, g in zip(want, got):
+        assert (g[0].numpy() == w[0]).all() and (g[1].numpy() == w[1]).all()
+
+    def broken():
+        yield (np.zeros(2),)
+        raise RuntimeError("disk gone")
+
+    pf = D.Prefetcher(broken(), lambda ts: tuple(ts), "cpu")
+    next(pf)                                                            # the good batch arrives ...
+    with pytest.raises(RuntimeError, match="disk gone"):
+        next(pf)                                                        # ... the failure when the next one is asked for
+    pf.close()
+    pf = D.Prefetcher(iter([(np.ones(1),)]), lambda ts: tuple(ts), "cpu")
+    assert len(list(pf)) == 1                                           # a finite stream ends the iteration
+
+
+def test_default_transforms():
+    from distributed_tensorflow_amd.models import get_model_module
+
+    x, y = _digits(6)
+    f = D.transform_for(get_model_module("mnist_mlp"), D.ArrayDataset([x, y], kind="mnist"), "cpu")
+    bx, by = f([torch.from_numpy(x), torch.from_numpy(y)])
+    assert bx.shape == (6, 784) and bx.dtype == torch.float32 and float(bx.max()) <= 1.0 and by.dtype == torch.int64
+    img = np.random.default_rng(0).integers(0, 256, (4, 16, 12, 3), dtype=np.uint8)
+    lab = np.arange(4, dtype=np.int32)
+    f = D.transform_for(get_model_module("resnet50"), D.ArrayDataset([img, lab], kind="images"), "cpu")
+    bx, by = f([torch.from_numpy(img), torch.from_numpy(lab)])
+    assert bx.shape == (4, 3, 16, 12) and bx.is_contiguous(memory_format=torch.channels_last) and by.dtype == torch.int64
+    want = (img[2, 5, 7, 1] / 255.0 - 0.456) / 0.224
+    assert abs(float(bx[2, 1, 5, 7]) - want) < 1e-5
+    nchw = torch.randn(4, 3, 8, 8)
+    bx, _ = f([nchw, torch.from_numpy(lab)])
+    assert torch.equal(bx, nchw)                                         # float NCHW input passes through
+
+
+def test_train_loop_takes_a_new_batch_every_step():
+    """``synthetic_batches`` / dataset input: the loop consumes the iterator, one batch per step, starting with ``batch``."""
+    from distributed_tensorflow_amd.models import get_model_module
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+    from distributed_tensorflow_amd.train.trainer import train_loop
+
+    mod = get_model_module("mnist_mlp")
+    torch.manual_seed(0)
+    model = mod.build()
+    ps = ShardedPS(list(model.named_parameters()), None, mod.default_optimizer())
+    bs = [mod.synthetic_batch(16, seed=s) for s in range(3)]
+    seen = []
+    orig = mod.loss_fn
+
+    def spy(m, b):
+        seen.append(int(b[1].sum()))
+        return orig(m, b)
+
+    mod.loss_fn = spy
+    try:
+        cyc = D.Cycle(bs)
+        first = next(cyc)
+        train_loop(model, mod, ps, first, 7, log_every=0, batches=cyc)
+    finally:
+        mod.loss_fn = orig
+    assert seen == [int(bs[i % 3][1].sum()) for i in range(7)]
+
+
+@pytest.mark.slow
+def test_rest_job_trains_mnist_from_idx_files_in_its_data_directory(tmp_path):
+    """Config #1 with real input plumbing: POST a job whose ``data`` directory holds MNIST-format IDX files; two workers
+    shard it, the loss falls well below a fixed-batch run's noise, and the log names the dataset."""
+    from distributed_tensorflow_amd.service.disTf import AllInOne
+    from distributed_tensorflow_amd.utils.config import ApiConfig
+    from distributed_tensorflow_amd.utils.naming import parse_task_name
+
+    x, y = _digits(4096, seed=3)
+    data = tmp_path / "mnist"
+    data.mkdir()
+    D.write_idx(str(data / "train-images-idx3-ubyte.gz"), x)
+    D.write_idx(str(data / "train-labels-idx1-ubyte.gz"), y)
+    ApiConfig.override("launcher", "grace_seconds", "1")
+    a = AllInOne(gpus=[], log_dir=str(tmp_path / "tasks"))
+    port = a.start(port=0)
+    try:
+        body = {"file": "builtin://mnist_mlp?steps=60&batch=64&placement=colocated&optimizer=momentum&lr=0.05&log_every=20",
+                "data": str(data), "detail": {"ps": 1, "worker": 2}}
+        req = urllib.request.Request("http://127.0.0.1:%d/v1/train" % port, data=json.dumps(body).encode(), method="POST")
+        with urllib.request.urlopen(req, timeout=30) as r:
+            names = json.loads(r.read().decode())
+        uid = parse_task_name(names[0])[0]
+        t0 = time.time()
+        rec = {}
+        while time.time() - t0 < 180:
+            rec = json.loads(a.store.get(uid))
+            if "t_cleaned" in rec:
+                break
+            time.sleep(0.2)
+        logs = ""
+        d = a.cluster._log_dir
+        for f in sorted(os.listdir(d)):
+            logs += open(os.path.join(d, f), errors="replace").read()
+        assert rec.get("status") == "succeeded", (rec, logs[-3000:])
+        assert "input: 4096 samples from" in logs and "(mnist), 32 steps per epoch" in logs, logs[-3000:]
+        m = a.store.hgetall(uid + ":metrics")
+        assert float(m["first_loss"]) > 1.5 and float(m["final_loss"]) < 0.5, m
+    finally:
+        a.stop()
+
+
+@pytest.mark.gpu
+def test_prefetcher_on_the_gpu_matches_the_host_transform():
+    """uint8 NHWC images through the pinned-host -> copy-stream -> normalise path while the training stream is busy: every
+    batch equals the CPU transform of the same rows (bf16, channels-last), labels int64."""
+    from distributed_tensorflow_amd.models import get_model_module
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (256, 24, 20, 3), dtype=np.uint8)
+    lab = rng.integers(0, 1000, 256).astype(np.int32)
+    ds = D.ArrayDataset([img, lab], kind="images")
+    mod = get_model_module("resnet50")
+    pf = D.Prefetcher(D.BatchStream(ds, 32, seed=2), D.transform_for(mod, ds, dev), dev)
+    ref_stream = D.BatchStream(ds, 32, seed=2)
+    cpu_f = D.transform_for(mod, ds, "cpu")
+    busy = torch.randn(4096, 4096, device=dev)
+    for _ in range(12):
+        busy = busy @ busy * 1e-4                       # keep the compute stream occupied between batches
+        bx, by = next(pf)
+        rx, ry = cpu_f([torch.from_numpy(a) for a in next(ref_stream)])
+        assert bx.dtype == torch.bfloat16 and bx.is_contiguous(memory_format=torch.channels_last) and by.dtype == torch.int64
+        torch.testing.assert_close(bx.float().cpu(), rx.to(torch.bfloat16).float(), rtol=0, atol=0)
+        assert torch.equal(by.cpu(), ry)
+    pf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_training_from_a_dataset_on_the_gpu(graph, tmp_path):
+    """mnist_mlp on the GPU fed by the prefetcher from IDX files, eagerly and with the step captured in a hipGraph (new
+    batches are copied into the captured input tensors): the loss falls on data that changes every step."""
+    from distributed_tensorflow_amd.models import get_model_module
+    from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec, ShardedPS
+    from distributed_tensorflow_amd.train.trainer import train_loop
+
+    dev = torch.device("cuda", 0)
+    x, y = _digits(2048, seed=4)
+    D.write_idx(str(tmp_path / "train-images-idx3-ubyte"), x)
+    D.write_idx(str(tmp_path / "train-labels-idx1-ubyte"), y)
+    ds = D.open_dataset(str(tmp_path))
+    mod = get_model_module("mnist_mlp")
+    torch.manual_seed(0)
+    model = mod.build().to(dev)
+    ps = ShardedPS(list(model.named_parameters()), None, OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9))
+    pf = D.Prefetcher(D.BatchStream(ds, 64, seed=0), D.transform_for(mod, ds, dev), dev)
+    first = next(pf)
+    losses = []
+    train_loop(model, mod, ps, first, 40, log_every=0, graph=graph, batches=pf,
+               on_step=lambda step, loss: losses.append(loss.detach().float().clone()))
+    pf.close()
+    ls = [float(v) for v in losses]
+    assert ls[0] > 1.5 and sum(ls[-5:]) / 5 < 0.5, ls

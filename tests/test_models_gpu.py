@@ -392,3 +392,33 @@ def test_resnet50_routing_table_at_the_bench_shape_is_the_recorded_one(dev):
     # left with exactly the three strided data gradients and the one 1x1 forward it wins
     lib = [l for l in got if l.rstrip().endswith("MIOpen")]
     assert len(lib) == 4 and not any(l.startswith("wgrad") for l in lib), lib
+
+
+def test_train_loop_with_the_step_in_a_hipgraph_equals_the_eager_loop(dev):
+    """``trainer.train_loop(graph=True)`` -- the loop behind a REST job with ``graph=1`` -- on ResNet-50: three eager steps
+    (on a side stream: after warm-up steps on the default stream hipStreamEndCapture crashed the process, which is how
+    every GPU job with ``graph=1`` ended before this test existed), capture, replay; parameters, BatchNorm buffers and
+    momentum equal the all-eager loop bit for bit."""
+    import copy
+
+    from distributed_tensorflow_amd.models import get_model_module
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+    from distributed_tensorflow_amd.train.trainer import train_loop
+
+    mod = get_model_module("resnet50")
+    torch.manual_seed(0)
+    m1 = mod.prepare(mod.build(), dev).train()
+    m2 = copy.deepcopy(m1)
+    batch = mod.synthetic_batch(64, device=dev, seed=3)      # 64: a batch size at which the default mode is reproducible
+    out = []
+    for m, graph in ((m1, False), (m2, True)):
+        ps = ShardedPS(list(m.named_parameters()), None, mod.default_optimizer())
+        ps.set_lr(0.02)
+        last, _, n = train_loop(m, mod, ps, batch, 9, log_every=0, graph=graph)
+        assert n == 9 and last == last
+        out.append((ps, last))
+        ps.remove_hooks()
+    assert out[0][1] == out[1][1]
+    assert torch.equal(out[0][0].master, out[1][0].master) and torch.equal(out[0][0].slot_m, out[1][0].slot_m)
+    for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+        assert torch.equal(b1, b2), n1
