@@ -1,0 +1,78 @@
+"""One all-in-one service on the GPU box, a sequence of REST jobs through the product path (POST /v1/train -> task ->
+trainer.run_task): checkpoint + resume, stale / async update modes, hipGraph, dataset input, the other model families,
+an injected worker failure.  Prints one line per job and writes gpurun_out/rest_matrix.json."""
+import json, os, sys, tempfile, time, urllib.request
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from distributed_tensorflow_amd.service.disTf import AllInOne
+from distributed_tensorflow_amd.utils.config import ApiConfig
+from distributed_tensorflow_amd.utils.naming import parse_task_name
+
+
+def http(port, method, path, body=None):
+    req = urllib.request.Request("http://127.0.0.1:%d%s" % (port, path), data=None if body is None else json.dumps(body).encode(),
+                                 method=method)
+    with urllib.request.urlopen(req, timeout=30) as r:
+        return json.loads(r.read().decode())
+
+
+ApiConfig.override("launcher", "grace_seconds", "3")
+logs = os.path.join("gpurun_out", "rest_matrix_tasks")
+aio = AllInOne(gpus=[0], log_dir=logs)
+port = aio.start(port=0)
+t_w = time.time()
+while not aio.cluster._idle_used and time.time() - t_w < 60:
+    time.sleep(0.05)
+export = tempfile.mkdtemp(prefix="dtf-export-")
+data = tempfile.mkdtemp(prefix="dtf-data-")
+rng = np.random.default_rng(0)
+np.save(os.path.join(data, "images.npy"), rng.integers(0, 256, (512, 224, 224, 3), dtype=np.uint8))
+np.save(os.path.join(data, "labels.npy"), rng.integers(0, 1000, 512).astype(np.int64))
+R = "builtin://resnet50?batch=64&log_every=4&"
+jobs = [
+    ("checkpoint every 8 steps", {"file": R + "steps=24&ckpt_every=8", "export": export}),
+    ("resume to step 36", {"file": R + "steps=36&resume=1", "export": export}),
+    ("stale-2", {"file": R + "steps=20&update_mode=stale&staleness=2"}),
+    ("one-sided async", {"file": R + "steps=20&update_mode=async"}),
+    ("hipGraph", {"file": R + "steps=20&graph=1"}),
+    ("dataset input (images.npy)", {"file": R + "steps=16", "data": data}),
+    ("dataset input + hipGraph", {"file": R + "steps=16&graph=1", "data": data}),
+    ("inception_v3", {"file": "builtin://inception_v3?batch=32&steps=10&log_every=5"}),
+    ("bert seq 128", {"file": "builtin://bert_base?batch=8&steps=10&seq_len=128&log_every=5"}),
+    ("wide_deep", {"file": "builtin://wide_deep?batch=8192&steps=20&log_every=10"}),
+    ("injected failure at step 5", {"file": R + "steps=20&fault=exit:worker=0,step=5,code=17"}),
+    ("after the failure", {"file": R + "steps=8"}),
+]
+out = []
+for name, spec in jobs:
+    body = {"type": "tensorflow", "data": "/synthetic", "resource": {"cpu": 8, "mem": "32g", "gpu": 1}, "detail": {"ps": 1, "worker": 1}}
+    body.update(spec)
+    t0 = time.time()
+    names = http(port, "POST", "/v1/train", body)
+    uid = parse_task_name(names[0])[0]
+    rec = {}
+    while time.time() - t0 < 240:
+        rec = http(port, "GET", "/v1/train?uid=" + uid)
+        if "t_cleaned" in rec:
+            break
+        time.sleep(0.2)
+    m = rec.get("metrics", {})
+    log = ""
+    for f in sorted(os.listdir(logs)):
+        if uid in f and "worker" in f:
+            log = open(os.path.join(logs, f), errors="replace").read()
+    notes = [k for k in ("resumed from step", "captured in a hipGraph", "input:", "wrote checkpoint", "injecting") if k in log]
+    rcl = rec.get("hbm_reclaim") or []
+    row = {"job": name, "status": rec.get("status"), "reason": rec.get("reason"), "step": m.get("step"),
+           "first_loss": m.get("first_loss"), "final_loss": m.get("final_loss"), "items_per_sec": m.get("items_per_sec"),
+           "seconds": round(time.time() - t0, 1), "log_notes": notes,
+           "hbm_reclaimed": [r.get("reclaimed") for r in rcl]}
+    out.append(row)
+    print("%-30s %-10s step %-4s loss %s -> %s  %s  reclaimed %s  %.1f s %s" % (
+        name, row["status"], row["step"], str(row["first_loss"])[:6], str(row["final_loss"])[:6], notes, row["hbm_reclaimed"],
+        row["seconds"], ("(" + str(row["reason"]) + ")") if row["reason"] else ""), flush=True)
+aio.stop()
+json.dump(out, open(os.path.join("gpurun_out", "rest_matrix.json"), "w"), indent=1)
+bad = [r["job"] for r in out if (r["status"] != "succeeded") != ("failure" in r["job"] and "after" not in r["job"])]
+print("unexpected outcomes:", bad)
+sys.exit(1 if bad else 0)
