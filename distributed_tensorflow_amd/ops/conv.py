@@ -1050,7 +1050,8 @@ class _ConvFn(torch.autograd.Function):
         strided_dx = None
         if (_DETERMINISTIC_STRICT and ctx.needs_input_grad[0] and not use_fwd and stride[0] == stride[1] and stride[0] > 1
                 and x.is_cuda and dy.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
-                and padding[0] <= weight.shape[2] - 1 and padding[1] <= weight.shape[3] - 1):
+                and padding[0] <= weight.shape[2] - 1 and padding[1] <= weight.shape[3] - 1
+                and weight.shape[0] % 32 == 0 and weight.shape[1] % 8 == 0):          # what K13 takes as (Cin, Cout) of the flipped filter
             # strict mode: the data gradient of a strided layer (ResNet's three 3x3 / 2 layers) as the stride-1 data gradient
             # of dY spread out with zeros between its pixels -- s^2 times the arithmetic of the library's strided kernel
             # plus one pass to build the spread tensor, but on K13 (fixed summation order) at every batch size, where
@@ -1062,9 +1063,7 @@ class _ConvFn(torch.autograd.Function):
             OH, OW = dy.shape[2], dy.shape[3]
             up = torch.empty((N, dy.shape[1], hu, wu), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last).zero_()
             up[:, :, 0:sd * (OH - 1) + 1:sd, 0:sd * (OW - 1) + 1:sd].copy_(dy)
-            wt_ok = weight.shape[0] % 32 == 0 and weight.shape[1] % 8 == 0
-            if wt_ok:
-                strided_dx = dgrad_as_forward(up, weight, padding, force_own=True)
+            strided_dx = dgrad_as_forward(up, weight, padding, force_own=True)
         mask = [ctx.needs_input_grad[0] and not use_fwd and strided_dx is None,
                 ctx.needs_input_grad[1] and not use_tn and not use_img, False]
         if use_img:
