@@ -262,3 +262,51 @@ def test_training_from_a_dataset_on_the_gpu(graph, tmp_path):
     pf.close()
     ls = [float(v) for v in losses]
     assert ls[0] > 1.5 and sum(ls[-5:]) / 5 < 0.5, ls
+
+
+@pytest.mark.slow
+def test_rest_job_runs_a_user_script_with_the_reference_arguments(tmp_path):
+    """The reference's mode of use: ``file`` is a python script, run in every worker task with the nine task arguments
+    (handlers/train_handler.py:82-83) -- here examples/train_mnist_script.py, two workers, MNIST IDX files in ``data``,
+    ``export`` for its result.  The ps task is parked and reaped when the workers are done."""
+    from distributed_tensorflow_amd.service.disTf import AllInOne
+    from distributed_tensorflow_amd.utils.config import ApiConfig
+    from distributed_tensorflow_amd.utils.naming import parse_task_name
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    x, y = _digits(2048, seed=5)
+    data = tmp_path / "mnist"
+    data.mkdir()
+    D.write_idx(str(data / "train-images-idx3-ubyte"), x)
+    D.write_idx(str(data / "train-labels-idx1-ubyte"), y)
+    export = tmp_path / "export"
+    ApiConfig.override("launcher", "grace_seconds", "1")
+    a = AllInOne(gpus=[], log_dir=str(tmp_path / "tasks"))
+    port = a.start(port=0)
+    try:
+        body = {"file": os.path.join(root, "examples", "train_mnist_script.py"), "data": str(data), "export": str(export),
+                "detail": {"ps": 1, "worker": 2}}
+        req = urllib.request.Request("http://127.0.0.1:%d/v1/train" % port, data=json.dumps(body).encode(), method="POST")
+        with urllib.request.urlopen(req, timeout=30) as r:
+            names = json.loads(r.read().decode())
+        assert len(names) == 3
+        uid = parse_task_name(names[0])[0]
+        t0 = time.time()
+        rec = {}
+        while time.time() - t0 < 180:
+            rec = json.loads(a.store.get(uid))
+            if "t_cleaned" in rec:
+                break
+            time.sleep(0.2)
+        logs = ""
+        d = a.cluster._log_dir
+        for f in sorted(os.listdir(d)):
+            logs += open(os.path.join(d, f), errors="replace").read()
+        assert rec.get("status") == "succeeded", (rec, logs[-3000:])
+        res = json.load(open(export / "result.json"))
+        assert res["workers"] == 2 and res["dataset"] == 2048 and res["steps"] == 60
+        assert res["first_loss"] > 1.5 and res["final_loss"] < 0.5, res
+        assert "[worker 0] 60 steps" in logs and "[worker 1] 60 steps" in logs, logs[-3000:]
+        assert a.cluster.dns_map(uid) == {}                      # ps task reaped, services gone
+    finally:
+        a.stop()
