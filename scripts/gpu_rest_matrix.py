@@ -40,6 +40,8 @@ jobs = [
     ("inception_v3", {"file": "builtin://inception_v3?batch=32&steps=10&log_every=5"}),
     ("bert seq 128", {"file": "builtin://bert_base?batch=8&steps=10&seq_len=128&log_every=5"}),
     ("wide_deep", {"file": "builtin://wide_deep?batch=8192&steps=20&log_every=10"}),
+    ("user script (examples/)", {"file": os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                                                     "train_mnist_script.py"), "export": export + "-script"}),
     ("injected failure at step 5", {"file": R + "steps=20&fault=exit:worker=0,step=5,code=17"}),
     ("after the failure", {"file": R + "steps=8"}),
 ]
@@ -61,7 +63,7 @@ for name, spec in jobs:
     for f in sorted(os.listdir(logs)):
         if uid in f and "worker" in f:
             log = open(os.path.join(logs, f), errors="replace").read()
-    notes = [k for k in ("resumed from step", "captured in a hipGraph", "input:", "wrote checkpoint", "injecting") if k in log]
+    notes = [k for k in ("resumed from step", "captured in a hipGraph", "input:", "wrote checkpoint", "injecting", "steps on cuda") if k in log]
     rcl = rec.get("hbm_reclaim") or []
     row = {"job": name, "status": rec.get("status"), "reason": rec.get("reason"), "step": m.get("step"),
            "first_loss": m.get("first_loss"), "final_loss": m.get("final_loss"), "items_per_sec": m.get("items_per_sec"),
