@@ -1,0 +1,76 @@
+"""Does the whole stack LEARN something that generalises?  bench.py's fixed batch can be memorised by almost any update
+rule; here ResNet-50 (10 classes) trains on a generated dataset -- class k = a low-frequency pattern of its own under heavy
+pixel noise, different every image -- fed through the input pipeline (memory-mapped uint8 file, sharded stream,
+prefetcher), through ShardedPS with a live 1-rank communicator, weight-gradient side stream and pull prefetch, and is then
+evaluated (BatchNorm in inference mode: the moving statistics the training kernels maintained) on images it never saw.
+usage: convergence_check.py [steps] [batch]"""
+import os, sys, tempfile
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_tensorflow_amd.utils import miopen as miopen_cache
+miopen_cache.setup()
+import numpy as np
+import torch
+from distributed_tensorflow_amd.models import get_model_module
+from distributed_tensorflow_amd.parallel.comm import Comm
+from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec, ShardedPS
+from distributed_tensorflow_amd.train import data as D
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+S, NTRAIN, NTEST, K = 64, 6144, 1024, 10
+
+
+def make(n, seed):
+    rng = np.random.default_rng(seed)
+    y = rng.integers(0, K, n)
+    yy, xx = np.meshgrid(np.linspace(0, 1, S), np.linspace(0, 1, S), indexing="ij")
+    base = np.stack([np.sin(2 * np.pi * ((k % 5 + 1) * xx + (k // 5 + 1) * yy))[..., None] * np.array([1.0, -0.5, 0.25])[(np.arange(3) + k) % 3]
+                     for k in range(K)])                                   # [K, S, S, 3]
+    img = 128 + 40 * base[y] + 45 * rng.standard_normal((n, S, S, 3))       # signal well below the noise per pixel
+    return np.clip(img, 0, 255).astype(np.uint8), y.astype(np.int64)
+
+
+d = tempfile.mkdtemp(prefix="dtf-conv-")
+xtr, ytr = make(NTRAIN, 0)
+xte, yte = make(NTEST, 1)
+np.save(os.path.join(d, "images.npy"), xtr)
+np.save(os.path.join(d, "labels.npy"), ytr)
+comm = Comm.from_env(force=True)
+dev = comm.device
+mod = get_model_module("resnet50")
+torch.manual_seed(0)
+m = mod.prepare(mod.build(num_classes=K), dev).train()
+ps = ShardedPS(list(m.named_parameters()), comm, OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9, weight_decay=1e-4))
+ps.attach(m)
+ds = D.open_dataset(d)
+pf = D.Prefetcher(D.BatchStream(ds, B, seed=0), D.transform_for(mod, ds, dev), dev)
+tf = D.transform_for(mod, ds, dev)
+
+
+def accuracy(x, y):
+    m.eval()
+    hit = 0
+    with torch.no_grad():
+        for i in range(0, len(x), 256):
+            bx, by = tf([torch.from_numpy(x[i:i + 256]).to(dev), torch.from_numpy(y[i:i + 256]).to(dev)])
+            hit += int((m(bx).float().argmax(1) == by).sum())
+    m.train()
+    return hit / len(x)
+
+
+acc0 = accuracy(xte, yte)
+losses = []
+for it in range(steps):
+    ps.set_lr(0.05 * min(1.0, (it + 1) / 30.0))
+    loss = mod.loss_fn(m, next(pf))
+    loss.backward()
+    ps.step()
+    losses.append(loss.detach())
+pf.close()
+torch.cuda.synchronize()
+ls = [float(v) for v in losses]
+acc = accuracy(xte, yte)
+print("steps %d batch %d: loss %.3f -> %.3f (mean of last 10: %.3f); held-out accuracy %.3f -> %.3f (chance 0.100)" % (
+    steps, B, ls[0], ls[-1], sum(ls[-10:]) / 10, acc0, acc), flush=True)
+comm.close()
+sys.exit(0 if acc > 0.8 else 1)

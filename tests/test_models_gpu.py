@@ -422,3 +422,23 @@ def test_train_loop_with_the_step_in_a_hipgraph_equals_the_eager_loop(dev):
     assert torch.equal(out[0][0].master, out[1][0].master) and torch.equal(out[0][0].slot_m, out[1][0].slot_m)
     for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
         assert torch.equal(b1, b2), n1
+
+
+def test_resnet50_learns_a_dataset_and_generalises(dev):
+    """scripts/convergence_check.py (own process, live 1-rank RCCL group): ResNet-50 trained for 150 steps on a generated
+    10-class dataset through the input pipeline and the whole PS pipeline, then evaluated in inference mode on images it has
+    never seen: accuracy from chance (0.10) to > 0.8.  A fixed batch can be memorised by a wrong gradient; held-out
+    accuracy cannot."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "150", "128"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"held-out accuracy ([0-9.]+) -> ([0-9.]+)", r.stdout)
+    assert m and float(m.group(1)) < 0.3 and float(m.group(2)) > 0.8, r.stdout[-1000:]
