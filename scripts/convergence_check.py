@@ -3,7 +3,11 @@ rule; here ResNet-50 (10 classes) trains on a generated dataset -- class k = a l
 pixel noise, different every image -- fed through the input pipeline (memory-mapped uint8 file, sharded stream,
 prefetcher), through ShardedPS with a live 1-rank communicator, weight-gradient side stream and pull prefetch, and is then
 evaluated (BatchNorm in inference mode: the moving statistics the training kernels maintained) on images it never saw.
-usage: convergence_check.py [steps] [batch]"""
+usage: convergence_check.py [steps] [batch] [resnet50 | wide_deep]
+
+``wide_deep``: config #3 on a stream of fresh synthetic batches (Zipf-skewed ids; the label is the XOR of the parity of
+feature 0's id and the sign of dense feature 0, so it can only be predicted through a trained embedding row AND the deep
+tower), routed embeddings + sparse Adagrad on the tables, Adam on the tower; accuracy on a batch it never saw."""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from distributed_tensorflow_amd.utils import miopen as miopen_cache
@@ -17,6 +21,38 @@ from distributed_tensorflow_amd.train import data as D
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+which = sys.argv[3] if len(sys.argv) > 3 else "resnet50"
+if which == "wide_deep":
+    comm = Comm.from_env(force=True)
+    dev = comm.device
+    mod = get_model_module("wide_deep")
+    torch.manual_seed(0)
+    m = mod.prepare(mod.build(comm=comm, device=dev), dev).train()
+    ps = ShardedPS(list(m.named_parameters()), comm, mod.default_optimizer())
+    ps.attach(m)
+    held = mod.synthetic_batch(B, device=dev, seed=10 ** 6, model=m)
+
+    def acc_wd():
+        m.eval()
+        with torch.no_grad():
+            p = m(held[0], held[1]).squeeze(1).float() > 0
+        m.train()
+        return float((p == (held[2] > 0.5)).float().mean())
+
+    a0 = acc_wd()
+    ls = []
+    for it in range(steps):
+        loss = mod.loss_fn(m, mod.synthetic_batch(B, device=dev, seed=it, model=m))
+        loss.backward()
+        ps.step()
+        ls.append(loss.detach())
+    torch.cuda.synchronize()
+    ls = [float(v) for v in ls]
+    a1 = acc_wd()
+    print("wide_deep steps %d batch %d: loss %.4f -> %.4f; held-out accuracy %.3f -> %.3f (chance 0.500)" % (
+        steps, B, ls[0], sum(ls[-10:]) / 10, a0, a1), flush=True)
+    comm.close()
+    sys.exit(0 if a1 > 0.8 else 1)
 S, NTRAIN, NTEST, K = 64, 6144, 1024, 10
 
 

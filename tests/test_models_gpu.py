@@ -424,6 +424,25 @@ def test_train_loop_with_the_step_in_a_hipgraph_equals_the_eager_loop(dev):
         assert torch.equal(b1, b2), n1
 
 
+def test_wide_deep_learns_and_generalises(dev):
+    """scripts/convergence_check.py wide_deep: config #3 on a stream of fresh Zipf-skewed batches whose label needs a trained
+    embedding row AND the deep tower (XOR of an id's parity and a dense feature's sign), routed embeddings through a live
+    1-rank group, sparse Adagrad + Adam: accuracy on an unseen batch from 0.5 to > 0.8."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "300", "65536", "wide_deep"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"held-out accuracy ([0-9.]+) -> ([0-9.]+)", r.stdout)
+    assert m and float(m.group(1)) < 0.6 and float(m.group(2)) > 0.8, r.stdout[-1000:]
+
+
 def test_resnet50_learns_a_dataset_and_generalises(dev):
     """scripts/convergence_check.py (own process, live 1-rank RCCL group): ResNet-50 trained for 150 steps on a generated
     10-class dataset through the input pipeline and the whole PS pipeline, then evaluated in inference mode on images it has
