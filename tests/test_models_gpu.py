@@ -443,6 +443,25 @@ def test_wide_deep_learns_and_generalises(dev):
     assert m and float(m.group(1)) < 0.6 and float(m.group(2)) > 0.8, r.stdout[-1000:]
 
 
+def test_bert_learns_and_generalises(dev):
+    """scripts/convergence_check.py bert: a 4-layer BERT (K11 attention, K10 LayerNorm, K12 cross-entropy, K6T, the clipped
+    sharded AdamW path through a live 1-rank group) on generated two-word sentences with 15 % masked: masked-word accuracy
+    on unseen sentences from 0 to > 0.8 in 500 steps."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29735", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "500", "64", "bert"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"masked-word accuracy ([0-9.]+) -> ([0-9.]+)", r.stdout)
+    assert m and float(m.group(1)) < 0.1 and float(m.group(2)) > 0.8, r.stdout[-1000:]
+
+
 def test_resnet50_learns_a_dataset_and_generalises(dev):
     """scripts/convergence_check.py (own process, live 1-rank RCCL group): ResNet-50 trained for 150 steps on a generated
     10-class dataset through the input pipeline and the whole PS pipeline, then evaluated in inference mode on images it has
@@ -461,3 +480,37 @@ def test_resnet50_learns_a_dataset_and_generalises(dev):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     m = re.search(r"held-out accuracy ([0-9.]+) -> ([0-9.]+)", r.stdout)
     assert m and float(m.group(1)) < 0.3 and float(m.group(2)) > 0.8, r.stdout[-1000:]
+
+
+def test_bert_fused_graph_matches_the_plain_fp32_model(dev):
+    """Whole-model check for BERT (there was none): the GPU model (bf16; K6 / K6T GEMMs with fused bias + GELU epilogues,
+    K10 LayerNorm, K11 attention on the packed projection, K12 cross-entropy, dense-embedding gradient) against the SAME
+    module on the CPU in fp32, where every op is the plain PyTorch composition -- loss, and the gradient of every parameter
+    by relative norm, on one batch; a CONTROL run of the plain composition in bf16 on the GPU gives the error bf16 itself
+    causes."""
+    import copy
+
+    from distributed_tensorflow_amd.models import bert
+
+    torch.manual_seed(0)
+    kw = dict(layers=2, hidden=256, heads=4, intermediate=1024, vocab=3000, seq_len=128)
+    ref = bert.build(**kw).train()                                        # fp32, CPU: plain ops
+    batch = bert.synthetic_batch(8, device="cpu", seed=2, seq_len=128, vocab=3000)
+    fused = bert.prepare(copy.deepcopy(ref), dev).train()
+    l_ref = bert.loss_fn(ref, batch)
+    l_ref.backward()
+    gb = tuple(t.to(dev) for t in batch)
+    l_fused = bert.loss_fn(fused, gb)
+    l_fused.backward()
+    torch.cuda.synchronize()
+    assert abs(float(l_fused) - float(l_ref)) / float(l_ref) < 1e-2, (float(l_fused), float(l_ref))
+    worst = []
+    for (n, p), (_, q) in zip(fused.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and q.grad is not None, n
+        g, r = p.grad.float().cpu(), q.grad
+        if float(r.norm()) < 1e-6:
+            continue
+        worst.append((float((g - r).norm() / r.norm()), n))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 6e-2, worst[:5]
+    assert sum(w for w, _ in worst) / len(worst) < 2.5e-2, worst[:5]
