@@ -3,7 +3,7 @@ rule; here ResNet-50 (10 classes) trains on a generated dataset -- class k = a l
 pixel noise, different every image -- fed through the input pipeline (memory-mapped uint8 file, sharded stream,
 prefetcher), through ShardedPS with a live 1-rank communicator, weight-gradient side stream and pull prefetch, and is then
 evaluated (BatchNorm in inference mode: the moving statistics the training kernels maintained) on images it never saw.
-usage: convergence_check.py [steps] [batch] [resnet50 | wide_deep | bert]
+usage: convergence_check.py [steps] [batch] [resnet50 | inception_v3 | wide_deep | bert]
 
 ``bert``: a 4-layer BERT (hidden 256, 4 heads of 64: the K11 attention kernel, K10 LayerNorm, K12 cross-entropy, K6T, the
 clipped sharded AdamW path) on generated sentences that alternate between two words (a random word of a 2 000-word
@@ -113,7 +113,7 @@ if which == "wide_deep":
         steps, B, ls[0], sum(ls[-10:]) / 10, a0, a1), flush=True)
     comm.close()
     sys.exit(0 if a1 > 0.8 else 1)
-S, NTRAIN, NTEST, K = 64, 6144, 1024, 10
+S, NTRAIN, NTEST, K = (96 if which == "inception_v3" else 64), (3072 if which == "inception_v3" else 6144), 1024, 10
 
 
 def make(n, seed):
@@ -133,7 +133,7 @@ np.save(os.path.join(d, "images.npy"), xtr)
 np.save(os.path.join(d, "labels.npy"), ytr)
 comm = Comm.from_env(force=True)
 dev = comm.device
-mod = get_model_module("resnet50")
+mod = get_model_module(which)
 torch.manual_seed(0)
 m = mod.prepare(mod.build(num_classes=K), dev).train()
 ps = ShardedPS(list(m.named_parameters()), comm, OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9, weight_decay=1e-4))
@@ -166,7 +166,7 @@ pf.close()
 torch.cuda.synchronize()
 ls = [float(v) for v in losses]
 acc = accuracy(xte, yte)
-print("steps %d batch %d: loss %.3f -> %.3f (mean of last 10: %.3f); held-out accuracy %.3f -> %.3f (chance 0.100)" % (
-    steps, B, ls[0], ls[-1], sum(ls[-10:]) / 10, acc0, acc), flush=True)
+print("%s steps %d batch %d: loss %.3f -> %.3f (mean of last 10: %.3f); held-out accuracy %.3f -> %.3f (chance 0.100)" % (
+    which, steps, B, ls[0], ls[-1], sum(ls[-10:]) / 10, acc0, acc), flush=True)
 comm.close()
 sys.exit(0 if acc > 0.8 else 1)

@@ -462,6 +462,24 @@ def test_bert_learns_and_generalises(dev):
     assert m and float(m.group(1)) < 0.1 and float(m.group(2)) > 0.8, r.stdout[-1000:]
 
 
+def test_inception_v3_learns_a_dataset_and_generalises(dev):
+    """The same check as for ResNet-50 below on Inception-v3 (96 x 96 images; K21 for its stem layer, concatenating
+    BatchNorm, average pools, 1x7 / 7x1 layers on K13): held-out accuracy from chance to > 0.8 in 200 steps."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29737", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "200", "64", "inception_v3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    m = re.search(r"held-out accuracy ([0-9.]+) -> ([0-9.]+)", r.stdout)
+    assert m and float(m.group(1)) < 0.3 and float(m.group(2)) > 0.8, r.stdout[-1000:]
+
+
 def test_resnet50_learns_a_dataset_and_generalises(dev):
     """scripts/convergence_check.py (own process, live 1-rank RCCL group): ResNet-50 trained for 150 steps on a generated
     10-class dataset through the input pipeline and the whole PS pipeline, then evaluated in inference mode on images it has
@@ -475,8 +493,8 @@ def test_resnet50_learns_a_dataset_and_generalises(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "150", "128"], capture_output=True,
-                       text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "150", "128", "resnet50"],
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     m = re.search(r"held-out accuracy ([0-9.]+) -> ([0-9.]+)", r.stdout)
     assert m and float(m.group(1)) < 0.3 and float(m.group(2)) > 0.8, r.stdout[-1000:]
