@@ -136,8 +136,16 @@ dev = comm.device
 mod = get_model_module(which)
 torch.manual_seed(0)
 m = mod.prepare(mod.build(num_classes=K), dev).train()
-ps = ShardedPS(list(m.named_parameters()), comm, OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9, weight_decay=1e-4))
-ps.attach(m)
+mode, stale_k = os.environ.get("DTF_UPDATE_MODE", "sync"), int(os.environ.get("DTF_STALENESS", "1"))
+spec = OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9, weight_decay=1e-4)
+if mode == "async":
+    from distributed_tensorflow_amd.parallel.async_ps import AsyncPS
+
+    ps = AsyncPS(list(m.named_parameters()), comm, spec)
+else:
+    ps = ShardedPS(list(m.named_parameters()), comm, spec, update_mode=mode, staleness=stale_k)
+    if mode == "sync":
+        ps.attach(m)
 ds = D.open_dataset(d)
 pf = D.Prefetcher(D.BatchStream(ds, B, seed=0), D.transform_for(mod, ds, dev), dev)
 tf = D.transform_for(mod, ds, dev)
@@ -166,7 +174,7 @@ pf.close()
 torch.cuda.synchronize()
 ls = [float(v) for v in losses]
 acc = accuracy(xte, yte)
-print("%s steps %d batch %d: loss %.3f -> %.3f (mean of last 10: %.3f); held-out accuracy %.3f -> %.3f (chance 0.100)" % (
-    which, steps, B, ls[0], ls[-1], sum(ls[-10:]) / 10, acc0, acc), flush=True)
+print("%s %s%s steps %d batch %d: loss %.3f -> %.3f (mean of last 10: %.3f); held-out accuracy %.3f -> %.3f (chance 0.100)" % (
+    which, mode, ("-%d" % stale_k) if mode == "stale" else "", steps, B, ls[0], ls[-1], sum(ls[-10:]) / 10, acc0, acc), flush=True)
 comm.close()
 sys.exit(0 if acc > 0.8 else 1)
