@@ -25,6 +25,14 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 @pytest.fixture(scope="module")
 def dev():
     if not torch.cuda.is_available():
@@ -435,7 +443,7 @@ def test_wide_deep_learns_and_generalises(dev):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29733", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "300", "65536", "wide_deep"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -454,7 +462,7 @@ def test_bert_learns_and_generalises(dev):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29735", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "500", "64", "bert"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -472,7 +480,7 @@ def test_inception_v3_learns_a_dataset_and_generalises(dev):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29737", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "200", "64", "inception_v3"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -492,7 +500,7 @@ def test_resnet50_learns_a_dataset_and_generalises(dev):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("DTF_")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "convergence_check.py"), "150", "128", "resnet50"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
