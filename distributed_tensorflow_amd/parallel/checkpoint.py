@@ -166,10 +166,51 @@ def write_index(export_dir, step, world, variables, extra=None):
     with open(tmp, "w") as f:
         json.dump(doc, f)
     os.replace(tmp, p)
+    kept = prune(export_dir, KEEP, newest=step)
     with open(os.path.join(export_dir, "checkpoint.tmp"), "w") as f:
-        f.write('model_checkpoint_path: "%s-%d"\nall_model_checkpoint_paths: "%s-%d"\n' % (PREFIX, step, PREFIX, step))
+        f.write('model_checkpoint_path: "%s-%d"\n' % (PREFIX, step))
+        for s_ in kept:
+            f.write('all_model_checkpoint_paths: "%s-%d"\n' % (PREFIX, s_))
     os.replace(os.path.join(export_dir, "checkpoint.tmp"), os.path.join(export_dir, "checkpoint"))
     return p
+
+
+# How many complete checkpoints stay in an export directory (TF1 Saver's max_to_keep, default 5; 0 = all of them): a job
+# that checkpoints every N steps would otherwise fill the disk (12 checkpoints of ResNet-50 = 2.3 GB).  Set from the
+# job option `keep_checkpoints` by the trainer.
+KEEP = int(os.environ.get("DTF_KEEP_CHECKPOINTS", "5"))
+
+
+def checkpoint_steps(export_dir):
+    """Steps that have an index file (= complete checkpoints), ascending."""
+    out = []
+    pre, suf = PREFIX + "-", ".index"
+    for f in os.listdir(export_dir) if os.path.isdir(export_dir) else []:
+        if f.startswith(pre) and f.endswith(suf):
+            try:
+                out.append(int(f[len(pre):-len(suf)]))
+            except ValueError:
+                pass
+    return sorted(out)
+
+
+def prune(export_dir, keep, newest=None):
+    """Delete all files of the checkpoints older than the ``keep`` newest complete ones (never ``newest``, never files of
+    a step that has no index yet: its shards are still being written).  Called by whoever publishes the index (the
+    chief), after the new index is in place.  -> the steps that remain, ascending."""
+    steps = checkpoint_steps(export_dir)
+    if keep <= 0 or len(steps) <= keep:
+        return steps
+    drop = [s_ for s_ in steps[:-keep] if s_ != newest]
+    for s_ in drop:
+        pre = "%s-%d." % (PREFIX, s_)
+        for f in os.listdir(export_dir):
+            if f.startswith(pre):
+                try:
+                    os.remove(os.path.join(export_dir, f))
+                except OSError:
+                    pass
+    return [s_ for s_ in steps if s_ not in drop]
 
 
 def write_replicated(export_dir, step, replicated):

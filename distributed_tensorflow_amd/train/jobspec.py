@@ -36,6 +36,7 @@ class TrainOptions:
     lr: float = -1.0                # <0: model default
     optimizer: str = ""             # "": model default
     ckpt_every: int = 0             # 0: only at the end (when export is set)
+    keep_checkpoints: int = 5       # complete checkpoints kept in `export` (TF1 Saver's max_to_keep); 0: all
     resume: bool = False
     seed: int = 1234
     log_every: int = 10
@@ -48,7 +49,7 @@ class TrainOptions:
     extra: dict = field(default_factory=dict)
 
 
-_INT = {"steps", "batch", "ckpt_every", "seed", "log_every", "staleness", "synthetic_batches"}
+_INT = {"steps", "batch", "ckpt_every", "seed", "log_every", "staleness", "synthetic_batches", "keep_checkpoints"}
 _FLOAT = {"bucket_mb", "lr"}
 _BOOL = {"resume", "graph"}
 

@@ -276,6 +276,7 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
         metrics(t_comm_ready=time.time())
     wire = _wire_dtype(opts, device)
     opt = _optimizer(mod, opts)
+    ckpt.KEEP = int(opts.keep_checkpoints)
     export = export_dir if export_dir and export_dir not in ("/tmp", "") else (export_dir or "")
     do_ckpt = bool(export_dir) and export_dir != "/tmp"
 

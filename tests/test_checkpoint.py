@@ -93,3 +93,37 @@ def test_bert_qkv_is_listed_as_query_key_value(tmp_path):
     ckpt.restore_ps(ps2, str(tmp_path), tf_names=bert.tf_variable_names(m2))
     for (n, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
         torch.testing.assert_close(p2.detach(), p1.detach(), rtol=0, atol=0, msg=n)
+
+
+def test_old_checkpoints_are_pruned_like_tf_max_to_keep(tmp_path, monkeypatch):
+    """``keep_checkpoints`` (TF1 Saver's max_to_keep): after every published index only the newest K complete checkpoints
+    remain -- every file of the older ones is gone, shards of a step that has no index yet are left alone, the
+    ``checkpoint`` file lists what is there, and the newest one restores."""
+    import os
+
+    monkeypatch.setattr(ckpt, "KEEP", 3)
+    torch.manual_seed(0)
+    model = _ConvNet()
+    ps = ShardedPS(list(model.named_parameters()), None, OptimizerSpec(kind="momentum", lr=0.1, momentum=0.9))
+    export = str(tmp_path)
+    open(os.path.join(export, "model.ckpt-999.data-00000-of-00001"), "wb").write(b"in flight")   # no index: not ours to delete
+    for step in range(1, 8):
+        _train_a_bit(model, ps)
+        ckpt.save_ps(ps, export, step=step, replicated={"global_step": torch.tensor(step)})
+        assert ckpt.checkpoint_steps(export) == list(range(max(1, step - 2), step + 1))
+    files = sorted(os.listdir(export))
+    assert not any(f.startswith("model.ckpt-%d." % s) for s in (1, 2, 3, 4) for f in files), files
+    assert all(any(f.startswith("model.ckpt-%d." % s) for f in files) for s in (5, 6, 7))
+    assert "model.ckpt-999.data-00000-of-00001" in files
+    text = open(os.path.join(export, "checkpoint")).read()
+    assert 'model_checkpoint_path: "model.ckpt-7"' in text
+    assert [l for l in text.splitlines() if l.startswith("all_model")] == ['all_model_checkpoint_paths: "model.ckpt-%d"' % s for s in (5, 6, 7)]
+    assert ckpt.latest_step(export) == 7
+    model2 = _ConvNet()
+    ps2 = ShardedPS(list(model2.named_parameters()), None, OptimizerSpec(kind="momentum", lr=0.1, momentum=0.9))
+    assert ckpt.restore_ps(ps2, export).step == 7
+    assert torch.equal(ps2.master, ps.master)
+    monkeypatch.setattr(ckpt, "KEEP", 0)                      # 0: keep everything
+    for step in (8, 9, 10, 11):
+        ckpt.save_ps(ps, export, step=step)
+    assert ckpt.checkpoint_steps(export) == [5, 6, 7, 8, 9, 10, 11]
