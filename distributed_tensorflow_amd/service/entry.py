@@ -219,7 +219,9 @@ def _main_staged(t_start, argv, job_name, task_index, ps_csv, worker_csv, file_f
                        "MASTER_ADDR": addr, "MASTER_PORT": str(port)})
 
     put = _metrics_sink(uid)
-    if getattr(opts, "graph", False):
+    if getattr(opts, "graph", False) is True:
+        # (graph=auto keeps the eager step's eight queues: its trial then compares the replay with the eager step as it
+        # really runs, not with one whose weight-gradient stream shares a hardware queue with the compute stream)
         # a replayed whole-step hipGraph wants HIP's default hardware-queue count back (restore_hw_queues); a GPU-hot
         # warm rank initialised HIP long ago with the eager setting, where the replay measured 29 vs 21 ms: stay eager
         from .. import restore_hw_queues

@@ -19,6 +19,10 @@ from ..parallel.comm import Comm
 from ..parallel.ps_runtime import OptimizerSpec, ShardedPS
 
 
+# graph=auto keeps the replay only if it is at least this much faster than the eager step (a factor on the eager time)
+GRAPH_AUTO_MARGIN = float(os.environ.get("DTF_GRAPH_AUTO_MARGIN", "0.98"))
+
+
 def _wire_dtype(opts, device):
     if opts.wire_dtype in ("bf16", "bfloat16"):
         return torch.bfloat16
@@ -118,7 +122,9 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
                items_per_step=None, start_step=0, graph=False, batches=None):
     """Runs ``steps`` PS steps; returns (last_loss, seconds, steps_done).  ``graph=True``: after three eager steps
     the whole step (forward, backward, hook-launched PS pipeline incl. its collectives) is captured in one hipGraph
-    and replayed -- the ~600 launches of a step then cost the host one call (GPU only).
+    and replayed -- the ~600 launches of a step then cost the host one call (GPU only).  ``graph="auto"``: capture, then
+    time eager training steps against replayed ones (two phases of 8 each, the better counts) and keep the faster (all of them count as training steps; with
+    several ranks the decision is taken on the slowest rank's times, so every rank replays or none does).
 
     ``batches``: an iterator of device batches (``train/data.py``: the job's ``data`` directory through the prefetcher, or
     several synthetic batches); ``batch`` is then the first of them.  With ``graph=True`` every new batch is copied INTO
@@ -129,6 +135,10 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
     loss = None
     cur = {"b": batch}
     static_input = bool(graph) and dev.type == "cuda"
+    if static_input and batches is not None:
+        # the captured step reads these tensors forever and every new batch is copied into them: they must be nobody
+        # else's (a round-robin source would otherwise find its first batch overwritten when it comes round again)
+        cur["b"] = tuple(t.clone() if isinstance(t, torch.Tensor) else t for t in batch)
 
     def eager():
         out = mod.loss_fn(model, cur["b"])
@@ -148,17 +158,23 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
         else:
             cur["b"] = nb
 
-    replay, static_loss = None, None
+    replay, static_loss, trial = None, None, None
+    TRIAL = (("graph", 3, False), ("graph", 8, True), ("graph", 8, True))
+    PRE = 3 + (8 if graph == "auto" else 0)       # eager steps before the capture; in auto mode the last 8 are timed
+    pre_t0, eager_ms = None, None
     # the eager steps before a capture run on a side stream (the protocol torch.cuda.graph documents and bench.py follows):
     # captured after warm-up steps on the DEFAULT stream, hipStreamEndCapture crashed the process on ROCm 7.2
     warm = None
-    if graph and dev.type == "cuda" and steps > 3:
+    if graph and dev.type == "cuda" and steps > PRE:
         warm = torch.cuda.Stream(dev)
         warm.wait_stream(torch.cuda.current_stream(dev))
     for it in range(start_step, start_step + steps):
         _inject(fault, worker, it + 1)
-        warming = warm is not None and replay is None and graph and it - start_step < 3
+        warming = warm is not None and replay is None and graph and it - start_step < PRE
         if warming:
+            if graph == "auto" and it - start_step == 3:
+                torch.cuda.synchronize(dev)
+                pre_t0 = time.perf_counter()
             with torch.cuda.stream(warm):
                 next_batch(it == start_step)
                 loss = eager()
@@ -166,10 +182,14 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
                 on_step(it + 1, loss)
             continue
         next_batch(it == start_step)
-        if graph and dev.type == "cuda" and replay is None and it - start_step == 3:
+        if graph and dev.type == "cuda" and replay is None and it - start_step == PRE:
             if warm is not None:
                 torch.cuda.current_stream(dev).wait_stream(warm)
             torch.cuda.synchronize(dev)
+            if pre_t0 is not None:
+                # the eager step is timed BEFORE the capture: afterwards it measured 2-5 ms per step slower than in a
+                # process that never captured (scripts/train_loop_auto_probe.py), which would bias the choice
+                eager_ms = (time.perf_counter() - pre_t0) / (PRE - 3)
             time.sleep(0.5)             # the RCCL watchdog retires the earlier collectives (no event queries mid-capture)
             if hasattr(ps, "disable_prefetch"):
                 ps.disable_prefetch()
@@ -199,14 +219,49 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
             if float(ok.item()) >= 1.0:
                 replay = g
                 print("[train] step captured in a hipGraph", flush=True)
+                if graph == "auto" and eager_ms is not None and start_step + steps - it >= sum(n for _, n, _ in TRIAL) + 8:
+                    # which is faster HERE?  The next replays are timed (the first three are not, the better of two
+                    # phases counts) and compared with the eager steps timed before the capture
+                    trial = {"plan": list(TRIAL), "best": {"eager": eager_ms, "graph": 1e30}}
+                    trial["phase"], trial["left"], trial["timed"] = trial["plan"].pop(0)
+                    trial["n"], trial["t0"] = trial["left"], time.perf_counter()
             else:
                 graph, static_loss = False, None
-        if replay is not None:
+        if replay is not None and (trial is None or trial["phase"] == "graph"):
             replay.replay()
             ps.global_step += 1
             loss = static_loss
         else:
             loss = eager()
+        if trial is not None:
+            trial["left"] -= 1
+            if trial["left"] == 0:
+                torch.cuda.synchronize(dev)
+                now = time.perf_counter()
+                if trial["timed"]:
+                    trial["best"][trial["phase"]] = min(trial["best"][trial["phase"]], (now - trial["t0"]) / trial["n"])
+                if trial["plan"]:
+                    trial["phase"], trial["left"], trial["timed"] = trial["plan"].pop(0)
+                    trial["n"], trial["t0"] = trial["left"], time.perf_counter()
+                else:
+                    t = torch.tensor([trial["best"]["eager"], trial["best"]["graph"]], dtype=torch.float64, device=dev)
+                    comm = getattr(ps, "comm", None)
+                    if comm is not None and comm.live and comm.world_size > 1:
+                        import torch.distributed as dist
+
+                        comm.all_reduce(t, op=dist.ReduceOp.MAX)        # one decision for the job: the slowest rank's times
+                    te, tg = float(t[0]), float(t[1])
+                    keep = tg < te * GRAPH_AUTO_MARGIN
+                    print("[train] hipGraph trial: eager %.2f ms/step, replay %.2f ms/step -> %s" % (
+                        te * 1e3, tg * 1e3, "replaying" if keep else "staying eager"), flush=True)
+                    if not keep:
+                        # drop the graph and its private memory pool, and give the cached blocks of the warm-up stream
+                        # back: the eager loop continues on the default stream
+                        replay, static_loss, g = None, None, None
+                        loss = loss.detach().clone() if loss is not None else None
+                        torch.cuda.synchronize(dev)
+                        torch.cuda.empty_cache()
+                    trial = None
         if on_step is not None:
             on_step(it + 1, loss)
         if log_every and (it + 1) % log_every == 0:
@@ -430,7 +485,7 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
     try:
         last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
                                    fault=fault, on_step=on_step, items_per_step=items, start_step=start_step,
-                                   graph=opts.graph and placement != "dedicated" and not one_sided, batches=batches)
+                                   graph=opts.graph if (placement != "dedicated" and not one_sided) else False, batches=batches)
     finally:
         if batches is not None:
             batches.close()

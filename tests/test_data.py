@@ -310,3 +310,33 @@ def test_rest_job_runs_a_user_script_with_the_reference_arguments(tmp_path):
         assert a.cluster.dns_map(uid) == {}                      # ps task reaped, services gone
     finally:
         a.stop()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("margin,expect", [(0.98, "replaying"), (0.0, "staying eager")])
+def test_graph_auto_times_eager_against_replay_and_keeps_the_faster(margin, expect, capsys, monkeypatch):
+    """``graph=auto``: eager steps are timed before the capture, replays after it; the tiny MLP is host-bound, so the replay
+    wins -- unless the margin says it never may (0.0), which exercises the way back: graph and memory pool dropped, eager
+    steps continue on the default stream.  Either way the loop trains (changing batches) and ends with the same
+    parameters as the all-eager loop."""
+    from distributed_tensorflow_amd.models import get_model_module
+    from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec, ShardedPS
+    from distributed_tensorflow_amd.train import trainer
+
+    monkeypatch.setattr(trainer, "GRAPH_AUTO_MARGIN", margin)
+    dev = torch.device("cuda", 0)
+    mod = get_model_module("mnist_mlp")
+    ends = []
+    for graph in (False, "auto"):
+        torch.manual_seed(0)
+        model = mod.build().to(dev)
+        ps = ShardedPS(list(model.named_parameters()), None, OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9))
+        cyc = D.Cycle([mod.synthetic_batch(64, device=dev, seed=s) for s in range(5)])
+        first = next(cyc)
+        last, _, n = trainer.train_loop(model, mod, ps, first, 80, log_every=0, graph=graph, batches=cyc)
+        assert n == 80 and last < 0.2
+        ends.append(ps.master.clone())
+        ps.remove_hooks()
+    out = capsys.readouterr().out
+    assert "hipGraph trial: eager" in out and expect in out, out
+    assert torch.equal(ends[0], ends[1])
