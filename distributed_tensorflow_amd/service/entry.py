@@ -66,10 +66,17 @@ def resolve_placement(requested, num_ps, env):
 
     auto: GPU workers and no GPUs for the ps tasks -> colocated (every GPU rank is worker + PS shard host);
           ps tasks with their own GPUs, or a CPU job with ps tasks -> dedicated."""
-    if requested in ("colocated", "dedicated"):
-        return requested
     wg = int(env.get("DTF_JOB_WORKER_GPUS", env.get("DTF_NUM_GPUS", "0")) or 0)
     pg = int(env.get("DTF_JOB_PS_GPUS", "0") or 0)
+    if requested == "dedicated" and wg > 0 and pg == 0 and num_ps >= 1:
+        # GPU workers rendezvous over RCCL, a ps task without a device can only speak gloo: the group would never form
+        # (a job submitted like that on the GPU box sat silent until it was killed).  Every task sees the same job-level
+        # facts, so every task takes the same way out.
+        print("[entry] placement=dedicated needs ps tasks with their own GPUs (resource.ps_gpu) when the workers have "
+              "GPUs; this job's ps tasks have none: using the colocated placement", flush=True)
+        return "colocated"
+    if requested in ("colocated", "dedicated"):
+        return requested
     if num_ps < 1:
         return "colocated"
     if wg > 0 and pg == 0:

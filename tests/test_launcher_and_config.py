@@ -263,7 +263,12 @@ def test_placement_is_resolved_per_job_not_per_task():
     assert resolve_placement("auto", 2, {"DTF_JOB_WORKER_GPUS": "1", "DTF_JOB_PS_GPUS": "1", "DTF_NUM_GPUS": "0"}) == "dedicated"
     assert resolve_placement("auto", 1, {"DTF_JOB_WORKER_GPUS": "0", "DTF_JOB_PS_GPUS": "0"}) == "dedicated"
     assert resolve_placement("auto", 0, {"DTF_JOB_WORKER_GPUS": "0"}) == "colocated"
-    assert resolve_placement("dedicated", 1, envs[1]) == "dedicated"
+    # an explicit request stands -- except where the group could never form: GPU workers (RCCL) with device-less ps
+    # tasks (gloo only); both task kinds then take the colocated way (the job used to hang in its rendezvous)
+    assert resolve_placement("dedicated", 2, {"DTF_JOB_WORKER_GPUS": "1", "DTF_JOB_PS_GPUS": "1"}) == "dedicated"
+    assert resolve_placement("dedicated", 1, {"DTF_JOB_WORKER_GPUS": "0", "DTF_JOB_PS_GPUS": "0"}) == "dedicated"
+    assert [resolve_placement("dedicated", 1, e) for e in envs] == ["colocated", "colocated"]
+    assert resolve_placement("colocated", 1, envs[1]) == "colocated"
 
 
 def test_miopen_setup_restricts_solver_families(tmp_path, monkeypatch):
