@@ -164,6 +164,14 @@ class CleanJobHandler(EventHandler):
     def _job_failed(self, rc, tfId, reason, worker_cnt=None):
         if not rc.set("failed:seen:%s" % tfId, reason, nx=True):
             return
+        try:
+            # the failing task reports its exception into <uid>:metrics before it exits (service/entry.py)
+            errs = {k: v for k, v in (rc.hgetall("%s:metrics" % tfId) or {}).items() if str(k).startswith("error:")}
+            if errs:
+                k = sorted(errs)[0]
+                reason = "%s (%s: %s)" % (reason, str(k)[6:], errs[k])
+        except Exception:       # noqa: BLE001 -- the reason is a convenience, the failure handling is not
+            pass
         log.warning("job %s failed: %s", tfId, reason)
         self._update_record(rc, tfId, status="failed", reason=reason, t_failed=time.time())
         self._enqueue_cleanup(rc, tfId, worker_cnt, kill_workers=True, reason=reason)

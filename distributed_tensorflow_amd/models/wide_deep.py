@@ -85,9 +85,12 @@ class WideDeep(nn.Module):
         return self.logits(h).float() + wide + self.wide_dense(dense.to(e.dtype)).float()
 
 
+OPTIONS = ("num_features", "rows_per_table", "embedding_dim", "dense_features", "emb_optimizer", "emb_lr", "atomic",
+           "partition", "route", "capacity_factor")
+
+
 def build(comm=None, device=None, **kw):
-    allowed = ("num_features", "rows_per_table", "embedding_dim", "dense_features", "emb_optimizer", "emb_lr", "atomic",
-               "partition", "route", "capacity_factor")
+    allowed = OPTIONS
     args = {}
     for k in allowed:
         if k in kw:

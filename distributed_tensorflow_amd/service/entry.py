@@ -269,6 +269,10 @@ def _main_staged(t_start, argv, job_name, task_index, ps_csv, worker_csv, file_f
         rc = run_task(job_name=job_name, task_index=task_index, num_ps=P, num_workers=W, placement=placement,
                       opts=opts, data_dir=data_dir, export_dir=export_dir, metrics=put, t_start=t_start,
                       on_checkpoint=on_checkpoint)
+    except Exception as e:
+        # the job record carries WHY: "worker task ... failed" alone sends the user to a task log they may not have
+        put(**{"error:%s-%d" % (job_name, task_index): ("%s: %s" % (type(e).__name__, e))[:400]})
+        raise
     finally:
         # also on failure: checkpoints of a run that died are the ones somebody will want.  A failed task does not
         # publish a NEW pointer (it may be ahead of peers that never wrote their shard); data files still go up.

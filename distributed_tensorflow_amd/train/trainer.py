@@ -65,8 +65,23 @@ def _inject(fault, worker, step):
             raise RuntimeError("injected fault")
 
 
+def unknown_options(mod, extra):
+    """Keys of the job's query string that nothing reads: not a TrainOptions field (those never reach ``extra``), not a
+    named argument of the model's ``build``, not one of its ``OPTIONS``, not a synthetic-batch shape."""
+    import inspect
+
+    known = {"seq_len", "image_size"} | set(getattr(mod, "OPTIONS", ()))
+    known |= {n for n, p in inspect.signature(mod.build).parameters.items() if p.kind != p.VAR_KEYWORD}
+    return sorted(k for k in extra if k not in known), sorted(known - {"comm", "device"})
+
+
 def prepare_model(mod, opts, device, comm=None):
     kw = dict(opts.extra)
+    bad, known = unknown_options(mod, kw)
+    if bad:
+        # a typo ("step=100", "batchsize=512") would otherwise run the default silently
+        print("[train] WARNING: option(s) %s are not read by anything and were ignored (model options: %s; job options: "
+              "docs/SWITCHES.md)" % (", ".join(bad), ", ".join(known)), flush=True)
     if getattr(mod, "NEEDS_COMM", False):
         kw.update(comm=comm, device=device)
     model = mod.build(**kw)
@@ -202,8 +217,15 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
                     static_loss = eager()
             except Exception as e:      # noqa: BLE001 -- stay eager rather than fail the job
                 print("[train] hipGraph capture failed (%s); staying eager" % type(e).__name__, flush=True)
-                ok.zero_()
-                torch.cuda.synchronize(dev)
+                try:
+                    # an exception inside capture_end leaves the capture stream current: back to the default stream
+                    torch.cuda.set_stream(torch.cuda.default_stream(dev))
+                    ok.zero_()
+                    torch.cuda.synchronize(dev)
+                except Exception:       # noqa: BLE001
+                    raise RuntimeError("the hipGraph capture of the training step failed (%s: %s) and left the device "
+                                       "in capture mode; run this job without graph=1" % (
+                                           type(e).__name__, str(e).splitlines()[0] if str(e) else "")) from e
             comm = getattr(ps, "comm", None)
             if comm is not None and comm.live and comm.world_size > 1:
                 # every rank replays or none does: a rank replaying captured collectives against ranks issuing
@@ -482,10 +504,22 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
 
     remaining = max(0, opts.steps - start_step)
     items = opts.batch * num_workers
+    use_graph = opts.graph
+    if use_graph:
+        # a captured step replays ONE fixed sequence of kernels: a stale pipeline rotates through `staleness` staging
+        # slots and waits for events of earlier steps, the one-sided and dedicated runtimes talk to other processes from
+        # the host in the middle of a step
+        why = ("update_mode=stale" if getattr(ps, "update_mode", "") == "stale" else "update_mode=async" if one_sided
+               else "placement=dedicated" if placement == "dedicated" else "")
+        if why:
+            if chief:
+                print("[train] graph=%s ignored: a step with %s cannot be captured in one hipGraph" % (
+                    "auto" if use_graph == "auto" else 1, why), flush=True)
+            use_graph = False
     try:
         last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
                                    fault=fault, on_step=on_step, items_per_step=items, start_step=start_step,
-                                   graph=opts.graph if (placement != "dedicated" and not one_sided) else False, batches=batches)
+                                   graph=use_graph, batches=batches)
     finally:
         if batches is not None:
             batches.close()

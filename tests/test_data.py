@@ -210,6 +210,56 @@ def test_rest_job_trains_mnist_from_idx_files_in_its_data_directory(tmp_path):
         a.stop()
 
 
+@pytest.mark.slow
+def test_failed_job_names_the_exception_and_uncapturable_graph_requests_are_declined(tmp_path):
+    """Two things the option matrix on the GPU box showed (scripts/gpu_rest_matrix.py odd): a job that dies of an
+    exception said only "worker task ... failed" in its record -- it now carries the exception; and ``graph=1`` with
+    ``update_mode=stale`` tried a capture that cannot work -- it is now declined with a line in the log."""
+    from distributed_tensorflow_amd.service.disTf import AllInOne
+    from distributed_tensorflow_amd.utils.config import ApiConfig
+    from distributed_tensorflow_amd.utils.naming import parse_task_name
+
+    x, y = _digits(96, seed=3)
+    data = tmp_path / "mnist"
+    data.mkdir()
+    D.write_idx(str(data / "train-images-idx3-ubyte.gz"), x)
+    D.write_idx(str(data / "train-labels-idx1-ubyte.gz"), y)
+    ApiConfig.override("launcher", "grace_seconds", "1")
+    a = AllInOne(gpus=[], log_dir=str(tmp_path / "tasks"))
+    port = a.start(port=0)
+
+    def run(file, **kw):
+        body = {"file": file, "detail": {"ps": 1, "worker": 1}}
+        body.update(kw)
+        req = urllib.request.Request("http://127.0.0.1:%d/v1/train" % port, data=json.dumps(body).encode(), method="POST")
+        with urllib.request.urlopen(req, timeout=30) as r:
+            uid = parse_task_name(json.loads(r.read().decode())[0])[0]
+        t0 = time.time()
+        rec = {}
+        while time.time() - t0 < 120:
+            rec = json.loads(a.store.get(uid))
+            if "t_cleaned" in rec:
+                break
+            time.sleep(0.2)
+        logs = ""
+        for f in sorted(os.listdir(a.cluster._log_dir)):
+            if uid in f:
+                logs += open(os.path.join(a.cluster._log_dir, f), errors="replace").read()
+        return rec, logs
+
+    try:
+        rec, logs = run("builtin://mnist_mlp?steps=4&batch=128", data=str(data))
+        assert rec.get("status") == "failed", rec
+        assert "ValueError: dataset of 96 samples is smaller than one global batch" in rec.get("reason", ""), rec
+        assert "worker-0" in rec["reason"], rec
+        rec, logs = run("builtin://mnist_mlp?steps=8&batch=32&update_mode=stale&staleness=3&graph=1&stpes=80")
+        assert rec.get("status") == "succeeded", (rec, logs[-2000:])
+        assert "graph=1 ignored: a step with update_mode=stale cannot be captured" in logs, logs[-2000:]
+        assert "WARNING: option(s) stpes are not read by anything" in logs, logs[-2000:]     # a typo does not pass silently
+    finally:
+        a.stop()
+
+
 @pytest.mark.gpu
 def test_prefetcher_on_the_gpu_matches_the_host_transform():
     """uint8 NHWC images through the pinned-host -> copy-stream -> normalise path while the training stream is busy: every
