@@ -179,6 +179,7 @@ class _Task:
                        "startTime": None, "completionTime": None, "phase": "Pending"}
         self.deleted = False
         self.released = False      # its GPUs went back to the free list (exactly once)
+        self.gang, self.gang_gpus = None, 0     # job uid and the devices ALL its tasks need together (manifest.gen_job)
         self.log_path = None
         self.exit_code = None
         self.hbm_before = None     # sysfs / rocm-smi counters at start (when the container exposes them)
@@ -396,6 +397,8 @@ class LocalCluster:
             gpus = list(range(min(n, cap))) if n else []
         self._free_gpus = list(gpus)
         self._all_gpus = list(gpus)
+        self._gangs = {}            # job uid -> devices set aside for its tasks that have not started yet
+        self._gang_broken = set()   # jobs being torn down: no reservation any more
         self._log_dir = log_dir or cfg.get("launcher", "log_dir", "logs/tasks")
         self._python = python or sys.executable
         self._extra_env = dict(extra_env or {})
@@ -568,6 +571,16 @@ class LocalCluster:
             if t.requested_gpus > len(self._all_gpus) and self._all_gpus:
                 raise ApiException(422, "job %s requests %d %s, node has %d" % (
                     name, t.requested_gpus, "amd.com/gpu", len(self._all_gpus)))
+            ann = (body.get("metadata") or {}).get("annotations") or {}
+            try:
+                t.gang, t.gang_gpus = ann.get("dtf/gang") or None, int(ann.get("dtf/gang-gpus", 0) or 0)
+            except (TypeError, ValueError):
+                t.gang, t.gang_gpus = None, 0
+            if t.gang and t.gang_gpus > len(self._all_gpus) and self._all_gpus:
+                # its tasks need these devices AT THE SAME TIME: admitted, some would start, wait in the rendezvous for
+                # the ones that never can, and hold their devices until a deadline
+                raise ApiException(422, "the tasks of job %s need %d %s at once, node has %d" % (
+                    t.gang, t.gang_gpus, "amd.com/gpu", len(self._all_gpus)))
             self._jobs[(namespace, name)] = t
             self._emit("ADDED", t)
             self._schedule()
@@ -579,20 +592,35 @@ class LocalCluster:
             if t.proc is not None or t.deleted or t.status["phase"] != "Pending":
                 continue
             need = t.requested_gpus if self._all_gpus else 0
-            if need > len(self._free_gpus):
+            pool = self._free_gpus
+            if t.gang and t.gang_gpus > 0 and self._all_gpus and t.gang not in self._gang_broken:
+                # all-or-nothing per job: the first task that finds the WHOLE job's devices free sets them aside, the
+                # job's other tasks draw from that reservation; until then every task of the job (its device-less ps
+                # tasks too: they would sit in the rendezvous) stays Pending.  Two jobs submitted at the same moment
+                # can therefore never hold half of the node each and wait for the other half.
+                if t.gang not in self._gangs:
+                    if t.gang_gpus > len(self._free_gpus):
+                        continue
+                    if self._hot is not None:
+                        self._free_gpus.sort(key=lambda g: (not self._hot.is_ready(g), g))
+                    self._gangs[t.gang] = [self._free_gpus.pop(0) for _ in range(t.gang_gpus)]
+                    self._free_gpus.sort()
+                pool = self._gangs[t.gang]
+            if need > len(pool):
                 continue
             if need == 1 and self._hot is not None:
                 # prefer a device whose GPU-hot rank is ready
-                g = next((g for g in self._free_gpus if self._hot.is_ready(g)), self._free_gpus[0])
-                self._free_gpus.remove(g)
+                g = next((g for g in pool if self._hot.is_ready(g)), pool[0])
+                pool.remove(g)
                 t.gpus = [g]
             else:
-                t.gpus = [self._free_gpus.pop(0) for _ in range(need)]
+                t.gpus = [pool.pop(0) for _ in range(need)]
             try:
                 self._start(t)
             except Exception as e:  # spawn failure = failed job, not a dead service
                 log.exception("failed to start %s", t.name)
                 self._free_gpus.extend(t.gpus)
+                self._free_gpus.sort()
                 t.gpus = []
                 t.status.update(active=0, failed=1, phase="Failed", completionTime=time.time())
                 t.exit_code = -1
@@ -761,6 +789,22 @@ class LocalCluster:
         t.status["message"] = "DeadlineExceeded"
         self._kill(t)
 
+    def _gang_task_gone(self, t):
+        # caller holds the lock.  A task of a gang was deleted: the job is being torn down (cleanup, cancel, rollback
+        # of a half-created job).  Devices set aside for tasks that never started go back, and tasks of this job that
+        # arrive later are scheduled one by one.  The entry is dropped with the job's last task.
+        gang = getattr(t, "gang", None)
+        if not gang:
+            return
+        left = self._gangs.pop(gang, None)
+        if left:
+            self._free_gpus.extend(left)
+            self._free_gpus.sort()
+        if any(getattr(o, "gang", None) == gang for o in self._jobs.values()):
+            self._gang_broken.add(gang)
+        else:
+            self._gang_broken.discard(gang)
+
     def _release_gpus(self, t):
         # caller holds the lock.  Idempotent per task: a second call must not re-add a device that has been
         # handed to another task in the meantime (double release -> two tenants on one GPU)
@@ -877,6 +921,7 @@ class LocalCluster:
         with self._lock:
             self._jobs.pop((namespace, name), None)
             self._release_gpus(t)
+            self._gang_task_gone(t)
             t.status.update(active=0, phase="Deleted")
             self._emit("DELETED", t)
             self._schedule()

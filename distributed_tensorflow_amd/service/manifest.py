@@ -122,10 +122,15 @@ def gen_job(uid, work_type, seq, count, info, ps, workers, cfg=None):
     if info.get("timeout"):
         # job-level time limit (k8s activeDeadlineSeconds); the launcher fails the task when it expires
         spec_extra["activeDeadlineSeconds"] = int(info["timeout"])
+    # gang scheduling (service/launcher.py): the tasks of one job start together or not at all -- a worker that got its
+    # device and waits in the rendezvous for a peer that never gets one holds the device forever
+    detail = info.get("detail") or {}
+    gang_gpus = int(detail.get("worker", 0) or 0) * int(r.get("gpu", 0) or 0) \
+        + int(detail.get("ps", 0) or 0) * int(r.get("ps_gpu", 0) or 0)
     return {
         "apiVersion": "batch/v1",
         "kind": "Job",
-        "metadata": {"name": tf_id},
+        "metadata": {"name": tf_id, "annotations": {"dtf/gang": str(uid), "dtf/gang-gpus": str(gang_gpus)}},
         "spec": {
             "backoffLimit": 0,
             **spec_extra,

@@ -36,6 +36,17 @@ def cluster(tmp_path):
 
 
 @pytest.fixture
+def cluster3(tmp_path):
+    ApiConfig.override("image", "tensorflow", "tests.fake_task")
+    ApiConfig.override("launcher", "grace_seconds", "0.3")
+    ApiConfig.override("launcher", "verify_reclaim", "0")
+    c = LocalCluster(gpus=[0, 1, 2], log_dir=str(tmp_path), extra_env={"PYTHONPATH": ROOT})
+    yield c
+    c.shutdown()
+    ApiConfig.override("launcher", "verify_reclaim", "1")
+
+
+@pytest.fixture
 def probing_cluster(tmp_path, monkeypatch):
     """Two fake devices with the HBM verification ON, the hipMemGetInfo child replaced by a slow fake: the window
     between 'task killed' and 'devices released' is then wide enough to race against."""
@@ -135,7 +146,64 @@ def test_event_log_is_bounded(cluster):
 
 def _job(seq, count, gpu, file_field="sleep:0.4"):
     info = {"file": file_field, "resource": {"gpu": gpu}, "detail": {"ps": 0, "worker": count}}
-    return manifest.gen_job(UID, "worker", seq, count, info, "", "")
+    body = manifest.gen_job(UID, "worker", seq, count, info, "", "")
+    body["metadata"].pop("annotations")       # these tests schedule each task by itself (no gang, see the gang tests below)
+    return body
+
+
+def _gang(uid, workers, gpu=1, ps=0, ps_gpu=0, file_field="sleep:0.4"):
+    info = {"file": file_field, "resource": {"gpu": gpu, "ps_gpu": ps_gpu}, "detail": {"ps": ps, "worker": workers}}
+    return manifest.gen_all(uid, info)[1]
+
+
+def test_tasks_of_one_job_get_their_devices_together_or_not_at_all(cluster3):
+    """Gang scheduling.  Two 2-GPU jobs whose tasks arrive interleaved on a 3-GPU node: without a reservation each
+    would start one task, the third device would go to whoever comes next, and the loser would wait in its rendezvous
+    holding a device.  With it the first job owns two devices from its first task on, the second job's tasks (its
+    device-less ps task too) stay Pending until two devices are free, then all start."""
+    c = cluster3
+    if True:
+        ja = _gang("11111111-aaaa-11f1-8000-000000000001", 2, file_field="sleep:1.0")
+        jb = _gang("22222222-bbbb-11f1-8000-000000000002", 2, ps=1, file_field="sleep:0.3")
+        a0 = c.create_namespaced_job("default", ja[0])
+        b_ps = c.create_namespaced_job("default", jb[0])          # job B's ps task: no device, still waits for the gang
+        b0 = c.create_namespaced_job("default", jb[1])
+        assert a0["status"]["gpus"] == [0] and c.free_gpus() == [2]            # device 1 is set aside for a1
+        assert b_ps["status"]["phase"] == "Pending" and b0["status"]["phase"] == "Pending"
+        b1 = c.create_namespaced_job("default", jb[2])
+        assert b1["status"]["phase"] == "Pending" and c.free_gpus() == [2]
+        a1 = c.create_namespaced_job("default", ja[1])
+        assert a1["status"]["gpus"] == [1]
+        names_b = [j["metadata"]["name"] for j in (b_ps, b0, b1)]
+        assert _wait(lambda: all(c.read_namespaced_job(n, "default")["status"]["succeeded"] == 1 for n in names_b[1:]), 20)
+        assert c.read_namespaced_job(names_b[0], "default")["status"]["phase"] == "Running"     # a ps task joins forever
+        got = sorted(g for n in names_b for g in c.read_namespaced_job(n, "default")["status"]["gpus"])
+        assert len(got) == 2 and len(set(got)) == 2
+        for j in (a0, a1, b_ps, b0, b1):
+            c.delete_namespaced_job(j["metadata"]["name"], "default")
+        assert c.free_gpus() == [0, 1, 2] and not c._gangs and not c._gang_broken
+
+
+def test_job_that_needs_more_devices_at_once_than_the_node_has_is_refused(cluster):
+    c = cluster
+    if True:
+        with pytest.raises(ApiException) as e:
+            c.create_namespaced_job("default", _gang("33333333-cccc-11f1-8000-000000000003", 3)[0])
+        assert e.value.status == 422 and "need 3 amd.com/gpu at once, node has 2" in e.value.reason
+        with pytest.raises(ApiException) as e:      # two workers and a ps task with a device of its own
+            c.create_namespaced_job("default", _gang("44444444-dddd-11f1-8000-000000000004", 2, ps=1, ps_gpu=1)[0])
+        assert e.value.status == 422
+        assert c.free_gpus() == [0, 1]
+
+
+def test_devices_set_aside_for_a_job_come_back_when_it_is_torn_down_half_created(cluster):
+    c = cluster
+    if True:
+        j = _gang("55555555-eeee-11f1-8000-000000000005", 2, file_field="sleep:5")
+        a0 = c.create_namespaced_job("default", j[0])
+        assert c.free_gpus() == []                 # one in use, one set aside
+        c.delete_namespaced_job(a0["metadata"]["name"], "default")         # submit rolled back / job cancelled
+        assert c.free_gpus() == [0, 1] and not c._gangs and not c._gang_broken
 
 
 def test_gpu_accounting_and_pending_jobs(cluster):
