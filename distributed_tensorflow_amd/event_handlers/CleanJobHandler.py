@@ -107,7 +107,8 @@ class CleanJobHandler(EventHandler):
             # a PS that exits by itself (signal from a worker, or a crash)
             if _get(eStatus, "failed"):
                 self._register(rc, "ps", tfId, cnt)
-                self._job_failed(rc, tfId, "ps task %s failed" % objName)
+                msg = _get(eStatus, "message")
+                self._job_failed(rc, tfId, "ps task %s failed%s" % (objName, (": %s" % msg) if msg else ""))
             return
         tfId, seq, cnt = self.searchPattern("worker", objName)
         if not tfId or self._is_final(rc, tfId):
@@ -123,7 +124,8 @@ class CleanJobHandler(EventHandler):
             else:
                 log.info("worker %s of %s done, %d remaining", seq, tfId, curCount)
         elif _get(eStatus, "failed"):
-            self._job_failed(rc, tfId, "worker task %s failed" % objName, worker_cnt=cnt)
+            msg = _get(eStatus, "message")          # the launcher's own verdict, e.g. DeadlineExceeded
+            self._job_failed(rc, tfId, "worker task %s failed%s" % (objName, (": %s" % msg) if msg else ""), worker_cnt=cnt)
 
     def _counts(self, rc, tfId, worker_cnt=None):
         psCnt = rc.hget(self._key("ps_key"), tfId)

@@ -18,17 +18,18 @@ def http(port, method, path, body=None):
 
 ApiConfig.override("launcher", "grace_seconds", "3")
 logs = os.path.join("gpurun_out", "rest_matrix_tasks")
-aio = AllInOne(gpus=[0], log_dir=logs)
+CPU = os.environ.get("DTF_MATRIX_CPU") == "1"          # rehearsal of the script itself on a box without a device
+aio = AllInOne(gpus=[] if CPU else [0], log_dir=logs)
 port = aio.start(port=0)
 t_w = time.time()
-while not aio.cluster._idle_used and time.time() - t_w < 60:
+while not CPU and not aio.cluster._idle_used and time.time() - t_w < 60:
     time.sleep(0.05)
 export = tempfile.mkdtemp(prefix="dtf-export-")
 data = tempfile.mkdtemp(prefix="dtf-data-")
 rng = np.random.default_rng(0)
 np.save(os.path.join(data, "images.npy"), rng.integers(0, 256, (512, 224, 224, 3), dtype=np.uint8))
 np.save(os.path.join(data, "labels.npy"), rng.integers(0, 1000, 512).astype(np.int64))
-R = "builtin://resnet50?batch=64&log_every=4&"
+R = "builtin://mnist_mlp?batch=64&log_every=4&" if CPU else "builtin://resnet50?batch=64&log_every=4&"
 jobs = [
     ("checkpoint every 8 steps", {"file": R + "steps=24&ckpt_every=8", "export": export}),
     ("resume to step 36", {"file": R + "steps=36&resume=1", "export": export}),
@@ -64,6 +65,70 @@ if len(sys.argv) > 1 and sys.argv[1] == "odd":
         ("unknown model option", {"file": R + "steps=6&no_such_option=1"}),
         ("inception_v3 aux_logits", {"file": "builtin://inception_v3?batch=16&steps=6&aux_logits=1&log_every=3"}),
     ]
+if len(sys.argv) > 1 and sys.argv[1] == "edges":
+    # control-plane edges on the real device: two jobs at once on one GPU, a cancel mid-run, a deadline, an unsatisfiable gang
+    import urllib.error
+
+    def post(spec):
+        body = {"type": "tensorflow", "data": "/synthetic", "resource": {"cpu": 8, "mem": "32g", "gpu": 1}, "detail": {"ps": 1, "worker": 1}}
+        body.update(spec)
+        return parse_task_name(http(port, "POST", "/v1/train", body)[0])[0]
+
+    def wait(uid, limit=150):
+        t0 = time.time()
+        while time.time() - t0 < limit:
+            rec = http(port, "GET", "/v1/train?uid=" + uid)
+            if "t_cleaned" in rec:
+                return rec
+            time.sleep(0.2)
+        return dict(rec, status="HUNG")
+
+    ok = True
+    t0 = time.time()
+    a = post({"file": R + "steps=300"})
+    b = post({"file": R + "steps=40"})
+    time.sleep(1.0)
+    phases = {("A" if a in j["metadata"]["name"] else "B") + "-" + j["metadata"]["name"].split("-")[-3]: j["status"]["phase"]
+              for j in aio.cluster.list_namespaced_job(ApiConfig().get("namespace", "tensorflow"))["items"]}
+    ra, rb = wait(a), wait(b)
+    ta, tb = float(ra["metrics"]["t_step1"]), float(rb["metrics"]["t_step1"])
+    print("two jobs at once on one GPU: phases after 1 s %s; A %s, B %s; B's first step %.1f s after A's (A ran %s steps first)" % (
+        phases, ra["status"], rb["status"], tb - ta, ra["metrics"].get("step")), flush=True)
+    ok &= ra["status"] == "succeeded" and rb["status"] == "succeeded" and tb > ta
+    c = post({"file": R + "steps=100000&log_every=50"})
+    while "t_step1" not in http(port, "GET", "/v1/train?uid=" + c).get("metrics", {}):
+        time.sleep(0.1)
+    time.sleep(2.0)
+    t1 = time.time()
+    http(port, "DELETE", "/v1/train?uid=" + c)
+    rc_ = wait(c)
+    print("cancel mid-run: %s (%s) %.1f s after DELETE, step %s reached, HBM reclaimed %s" % (
+        rc_["status"], rc_.get("reason"), time.time() - t1, rc_["metrics"].get("step"),
+        [r.get("reclaimed") for r in rc_.get("hbm_reclaim") or []]), flush=True)
+    ok &= rc_["status"] == "failed" and rc_.get("reason") == "cancelled"
+    d = post({"file": R + "steps=50&fault=hang:worker=0,step=5", "timeout": 12})
+    rd = wait(d)
+    print("hung worker with timeout=12: %s (%s) after %.1f s, HBM reclaimed %s" % (
+        rd["status"], rd.get("reason"), float(rd.get("t_failed", 0)) - float(rd["metrics"]["t_submit"]),
+        [r.get("reclaimed") for r in rd.get("hbm_reclaim") or []]), flush=True)
+    ok &= rd["status"] == "failed"
+    try:
+        post({"file": R + "steps=5", "detail": {"ps": 1, "worker": 2}})
+        print("two 1-GPU workers on a 1-GPU node: ACCEPTED (wrong)")
+        ok = False
+    except urllib.error.HTTPError as e:
+        print("two 1-GPU workers on a 1-GPU node: HTTP %d %s" % (e.code, e.read().decode()), flush=True)
+    e_ = post({"file": R + "steps=8"})
+    re_ = wait(e_)
+    t_f = time.time()
+    while aio.cluster.free_gpus() != ([] if CPU else [0]) and time.time() - t_f < 20:
+        time.sleep(0.1)         # the finished worker's device comes back once the HBM probe has seen it empty
+    print("a plain job afterwards: %s, step %s, free devices %s, reservations %s" % (
+        re_["status"], re_["metrics"].get("step"), aio.cluster.free_gpus(), aio.cluster._gangs), flush=True)
+    ok &= re_["status"] == "succeeded" and aio.cluster.free_gpus() == ([] if CPU else [0])
+    aio.stop()
+    print("edges:", "all as intended" if ok else "SOMETHING WRONG", "(%.0f s)" % (time.time() - t0))
+    sys.exit(0 if ok else 1)
 out = []
 for name, spec in jobs:
     body = {"type": "tensorflow", "data": "/synthetic", "resource": {"cpu": 8, "mem": "32g", "gpu": 1}, "detail": {"ps": 1, "worker": 1}}

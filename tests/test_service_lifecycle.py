@@ -166,4 +166,5 @@ def test_job_timeout_kills_hung_workers_and_cleans_up(aio):
     uid = parse_task_name(names[0])[0]
     rec = _wait(lambda: (lambda r: r if r.get("t_cleaned") else None)(json.loads(a.store.get(uid))), timeout=30)
     assert rec and rec["status"] == "failed"
+    assert "DeadlineExceeded" in rec["reason"], rec      # the record says WHY the task failed, not only that it did
     assert a.cluster.list_namespaced_job("default")["items"] == [] and a.cluster.dns_map(uid) == {}
