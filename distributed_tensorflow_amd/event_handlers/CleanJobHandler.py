@@ -125,6 +125,9 @@ class CleanJobHandler(EventHandler):
                 log.info("worker %s of %s done, %d remaining", seq, tfId, curCount)
         elif _get(eStatus, "failed"):
             msg = _get(eStatus, "message")          # the launcher's own verdict, e.g. DeadlineExceeded
+            code = _get(eStatus, "exitCode")
+            if not msg and code not in (None, 0, 1):
+                msg = "exit code %s" % code         # 1 = an exception, reported by the task itself (_job_failed)
             self._job_failed(rc, tfId, "worker task %s failed%s" % (objName, (": %s" % msg) if msg else ""), worker_cnt=cnt)
 
     def _counts(self, rc, tfId, worker_cnt=None):

@@ -121,7 +121,7 @@ def test_failed_worker_tears_down_whole_job(aio):
     uid = parse_task_name(names[0])[0]
     pids = [a.cluster._jobs[("default", n)].proc.pid for n in names]
     rec = _wait(lambda: (lambda r: r if r.get("t_cleaned") else None)(json.loads(a.store.get(uid))))
-    assert rec and rec["status"] == "failed" and "worker" in rec["reason"]
+    assert rec and rec["status"] == "failed" and "worker" in rec["reason"] and rec["reason"].endswith("failed: exit code 3"), rec
     assert _wait(lambda: not any(_alive(p) for p in pids)), "hung survivors must be killed"
     assert a.cluster.list_namespaced_job("default")["items"] == []
     assert a.cluster.dns_map(uid) == {}
