@@ -19,6 +19,7 @@ import torch
 
 ENABLED = os.environ.get("DTF_WGRAD_STREAM", "1") != "0"
 _DEBUG = int(os.environ.get("DTF_WGRAD_DEBUG", "0"))      # bisecting aid: 1 fresh event per call, 2 rejoin after every call
+_PRIORITY = int(os.environ.get("DTF_WGRAD_PRIORITY", "0"))
 _streams = {}
 _join_queued = set()
 _held = {}          # (device index, stream) -> tensors the side stream may still be reading
@@ -30,7 +31,9 @@ def wgrad_stream(device, create=True):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     s = _streams.get(key)
     if s is None and create:
-        s = _streams[key] = torch.cuda.Stream(device=device)
+        # DTF_WGRAD_PRIORITY: stream priority of the side stream (torch: lower number = served first; 0 = like the compute
+        # stream).  A positive value asks the hardware scheduler to give free CUs to the compute stream's kernels first.
+        s = _streams[key] = torch.cuda.Stream(device=device, priority=_PRIORITY)
     return s
 
 
