@@ -1,0 +1,184 @@
+"""The TF1-shaped surface for user scripts (``train/session.py``): ClusterSpec / Server / replica_device_setter /
+SyncReplicasOptimizer / MonitoredTrainingSession / StopAtStepHook -- the five names a script written for the reference's
+image uses -- and ``examples/mnist_replica.py`` run by hand (two worker processes, then a resumed run with
+ONE worker from the checkpoint the two wrote) and as the ``file`` of a REST job."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import time
+import urllib.request
+
+import pytest
+import torch
+
+from distributed_tensorflow_amd.models import mnist_mlp
+from distributed_tensorflow_amd.parallel import checkpoint as ckpt
+from distributed_tensorflow_amd.parallel.comm import Comm
+from distributed_tensorflow_amd.train import session as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCRIPT = os.path.join(ROOT, "examples", "mnist_replica.py")
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_cluster_spec_and_placement():
+    cs = S.ClusterSpec.from_lists("a:2222", "b:2222, c:2222,")
+    assert cs.jobs == ["ps", "worker"] and cs.num_tasks("worker") == 2 and cs.task_address("worker", 1) == "c:2222"
+    assert S.ClusterSpec(cs.as_dict()).as_dict() == {"ps": ["a:2222"], "worker": ["b:2222", "c:2222"]}
+    assert S.ClusterSpec({"worker": {0: "x:1", 1: "y:2"}}).job_tasks("worker") == ["x:1", "y:2"]
+    assert S.replica_device_setter(cluster=cs).num_shards == 1
+    assert S.replica_device_setter(ps_tasks=4).num_shards == 4
+    assert S.replica_device_setter().num_shards is None
+    with pytest.raises(ValueError, match="backup workers"):
+        S.SyncReplicasOptimizer("sgd", replicas_to_aggregate=3, total_num_replicas=4)
+    with pytest.raises(ValueError):
+        S.StopAtStepHook()
+
+
+def test_session_trains_checkpoints_and_restores(tmp_path):
+    """One process: the session equals the hand-written loop on ShardedPS step for step, saves every N steps and on
+    exit, and a second session over the same directory continues from the saved global_step with the saved variables."""
+    from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec, ShardedPS
+
+    def batches():
+        return [mnist_mlp.synthetic_batch(32, device="cpu", seed=k) for k in range(4)]
+
+    torch.manual_seed(0)
+    ref = mnist_mlp.build()
+    ps = ShardedPS(list(ref.named_parameters()), Comm.single(), OptimizerSpec(kind="momentum", lr=0.05, momentum=0.9))
+    ref_losses = []
+    for i in range(12):
+        loss = mnist_mlp.loss_fn(ref, batches()[i % 4])
+        loss.backward()
+        ps.step()
+        ref_losses.append(float(loss))
+
+    torch.manual_seed(0)
+    model = mnist_mlp.build()
+    d = str(tmp_path / "train")
+    got = []
+    with S.MonitoredTrainingSession(model, S.SyncReplicasOptimizer({"kind": "momentum", "lr": 0.05, "momentum": 0.9}),
+                                    comm=Comm.single(), checkpoint_dir=d, save_checkpoint_steps=5,
+                                    hooks=[S.StopAtStepHook(last_step=8)], tf_names=mnist_mlp.tf_variable_names(model)) as sess:
+        bs = batches()
+        while not sess.should_stop():
+            got.append(float(sess.run(mnist_mlp.loss_fn(model, bs[sess.global_step % 4]))))
+    assert got == ref_losses[:8]
+    assert ckpt.checkpoint_steps(d) == [5, 8] and ckpt.latest_step(d) == 8
+
+    torch.manual_seed(123)              # different initial values: the restore must replace them
+    model2 = mnist_mlp.build()
+    with S.MonitoredTrainingSession(model2, {"kind": "momentum", "lr": 0.05, "momentum": 0.9}, comm=Comm.single(),
+                                    checkpoint_dir=d, hooks=[S.StopAtStepHook(num_steps=4)],
+                                    tf_names=mnist_mlp.tf_variable_names(model2)) as sess:
+        assert sess.global_step == 8
+        bs = batches()
+        while not sess.should_stop():
+            got.append(float(sess.run(mnist_mlp.loss_fn(model2, bs[sess.global_step % 4]))))
+    assert len(got) == 12 and got == pytest.approx(ref_losses, rel=1e-6, abs=1e-7)
+    assert ckpt.latest_step(d) == 12
+
+
+def test_chief_must_be_worker_zero():
+    with pytest.raises(ValueError, match="is_chief must be worker 0"):
+        S.MonitoredTrainingSession(mnist_mlp.build(), "sgd", comm=Comm.single(), is_chief=False)
+
+
+def _run_workers(n, train_dir, steps, extra=()):
+    hosts = ",".join("127.0.0.1:%d" % _port() for _ in range(n))
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="2", DTF_NUM_GPUS="0", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, SCRIPT, "--job_name=worker", "--task_index=%d" % i, "--worker_hosts=" + hosts,
+                               "--train_dir=" + train_dir, "--train_steps=%d" % steps, "--batch_size=64", *extra],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(n)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-4000:]
+    return outs
+
+
+@pytest.mark.slow
+def test_mnist_replica_by_hand_two_workers_then_resumed_by_one(tmp_path):
+    """The sample as somebody runs it from a shell: flags, no service, no environment -- the cluster's worker 0 address
+    is the rendezvous.  Two workers train 120 steps and write the checkpoint; ONE worker then resumes it to 160."""
+    d = str(tmp_path / "train")
+    outs = _run_workers(2, d, 120)
+    assert all("global_step 120" in o for o in outs), outs
+    assert "terminate called" not in "".join(outs)
+    idx = ckpt.read_index(d)
+    assert idx["step"] == 120 and idx["world"] == 2 and "hid_w" in idx["variables"] and "hid_w/Momentum" in idx["variables"]
+    first = float(outs[0].split("loss ")[-1].split(" ->")[0])
+    last = float(outs[0].split("-> ")[-1].split(" ")[0])
+    assert first > 1.5 and last < 0.3, outs[0]
+    outs = _run_workers(1, d, 160)
+    assert "restored" in outs[0] and "global_step 160" in outs[0], outs[0]
+    resumed_first = float(outs[0].split("loss ")[-1].split(" ->")[0])
+    assert resumed_first < 0.5, outs[0]          # it continued, it did not start over
+    assert ckpt.latest_step(d) == 160 and ckpt.read_index(d)["world"] == 1
+
+
+@pytest.mark.slow
+def test_mnist_replica_as_the_file_of_a_rest_job(tmp_path):
+    from distributed_tensorflow_amd.service.disTf import AllInOne
+    from distributed_tensorflow_amd.utils.config import ApiConfig
+    from distributed_tensorflow_amd.utils.naming import parse_task_name
+
+    ApiConfig.override("launcher", "grace_seconds", "1")
+    a = AllInOne(gpus=[], log_dir=str(tmp_path / "tasks"), extra_env={"STEPS": "60", "BATCH": "64"})
+    port = a.start(port=0)
+    try:
+        export = str(tmp_path / "export")
+        body = {"file": SCRIPT, "export": export, "detail": {"ps": 1, "worker": 2}}
+        req = urllib.request.Request("http://127.0.0.1:%d/v1/train" % port, data=json.dumps(body).encode(), method="POST")
+        with urllib.request.urlopen(req, timeout=30) as r:
+            uid = parse_task_name(json.loads(r.read().decode())[0])[0]
+        t0 = time.time()
+        rec = {}
+        while time.time() - t0 < 180:
+            rec = json.loads(a.store.get(uid))
+            if "t_cleaned" in rec:
+                break
+            time.sleep(0.2)
+        logs = ""
+        for f in sorted(os.listdir(a.cluster._log_dir)):
+            logs += open(os.path.join(a.cluster._log_dir, f), errors="replace").read()
+        assert rec.get("status") == "succeeded", (rec, logs[-3000:])
+        assert logs.count("global_step 60") == 2, logs[-3000:]
+        assert ckpt.latest_step(export) == 60 and ckpt.read_index(export)["world"] == 2
+    finally:
+        a.stop()
+
+
+@pytest.mark.gpu
+def test_mnist_replica_on_the_gpu(tmp_path):
+    """The same script, one worker on the MI355X: variables, PS runtime and batches live on the device, the checkpoint
+    is written from there and a second run resumes it."""
+    d = str(tmp_path / "train")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, SCRIPT, "--job_name=worker", "--task_index=0", "--worker_hosts=127.0.0.1:%d" % _port(),
+           "--train_dir=" + d, "--batch_size=64"]
+    r = subprocess.run(cmd + ["--train_steps=120"], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "global_step 120 on cuda:0" in r.stdout, r.stdout
+    assert float(r.stdout.split("-> ")[-1].split(" ")[0]) < 0.3, r.stdout
+    r = subprocess.run(cmd + ["--train_steps=150"], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "restored" in r.stdout and "global_step 150 on cuda:0" in r.stdout, r.stdout
+    assert ckpt.latest_step(d) == 150
