@@ -127,3 +127,40 @@ def test_old_checkpoints_are_pruned_like_tf_max_to_keep(tmp_path, monkeypatch):
     for step in (8, 9, 10, 11):
         ckpt.save_ps(ps, export, step=step)
     assert ckpt.checkpoint_steps(export) == [5, 6, 7, 8, 9, 10, 11]
+
+
+def test_inspect_checkpoint_tool_lists_prints_and_exports(tmp_path, capsys):
+    """``python -m distributed_tensorflow_amd.tools.inspect_checkpoint`` (TF1's inspect_checkpoint for the `export`
+    directory of a job): listing with TF-style names and optimizer slots, one tensor, one-file export that another
+    program can load without this package."""
+    from safetensors.torch import load_file
+
+    from distributed_tensorflow_amd.models import mnist_mlp
+    from distributed_tensorflow_amd.parallel.comm import Comm
+    from distributed_tensorflow_amd.tools import inspect_checkpoint as tool
+    from distributed_tensorflow_amd.train import session as S
+
+    d = str(tmp_path / "export")
+    m = mnist_mlp.build()
+    with S.MonitoredTrainingSession(m, "momentum", comm=Comm.single(), checkpoint_dir=d,
+                                    hooks=[S.StopAtStepHook(last_step=3)], tf_names=mnist_mlp.tf_variable_names(m)) as sess:
+        while not sess.should_stop():
+            sess.run(mnist_mlp.loss_fn(m, mnist_mlp.synthetic_batch(8, device="cpu", seed=1)))
+    assert tool.main([d]) == 0
+    out = capsys.readouterr().out
+    assert "step 3, written by 1 rank(s), optimizer momentum" in out and "hid_w/Momentum" in out and "[784, 100]" in out
+    assert "global_step" in out and "8 variables, 159020 elements" in out
+    assert tool.main([d, "--tensor_name", "sm_b"]) == 0
+    assert "tensor_name: sm_b  shape [10]  dtype float32" in capsys.readouterr().out
+    assert tool.main([d, "--tensor_name", "nope"]) == 1 and tool.main([str(tmp_path / "nothing")]) == 1
+    capsys.readouterr()
+    f = str(tmp_path / "model.safetensors")
+    assert tool.main([d, "--export", f]) == 0
+    t = load_file(f)
+    assert sorted(t) == ["global_step", "hid_b", "hid_w", "sm_b", "sm_w"] and int(t["global_step"]) == 3
+    names = mnist_mlp.tf_variable_names(m)
+    for n, p in m.named_parameters():
+        assert torch.equal(t[names[n]], p.detach()), n
+    assert tool.main([d, "--export", str(tmp_path / "all.pt"), "--with_slots"]) == 0
+    allt = torch.load(str(tmp_path / "all.pt"), weights_only=True)
+    assert "hid_w/Momentum" in allt and allt["hid_w/Momentum"].shape == (784, 100)
