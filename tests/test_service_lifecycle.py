@@ -168,3 +168,25 @@ def test_job_timeout_kills_hung_workers_and_cleans_up(aio):
     assert rec and rec["status"] == "failed"
     assert "DeadlineExceeded" in rec["reason"], rec      # the record says WHY the task failed, not only that it did
     assert a.cluster.list_namespaced_job("default")["items"] == [] and a.cluster.dns_map(uid) == {}
+
+
+def test_command_line_client_submits_waits_reports_and_cancels(aio, capsys):
+    """``python -m distributed_tensorflow_amd.tools.job``: submit --wait of a job that succeeds (exit 0), of one that fails
+    (exit 1, the reason printed), status listing, cancel of a running one, a refused spec (exit 1, the service's message)."""
+    from distributed_tensorflow_amd.tools import job
+
+    a, port = aio
+    url = "http://127.0.0.1:%d" % port
+    assert job.main(["--url", url, "submit", "--file", "sleep:0.3", "--worker", "2", "--wait", "--wait-limit", "60"]) == 0
+    out = capsys.readouterr().out
+    assert "uid " in out and out.count("  task tf-") == 3 and "succeeded" in out
+    assert job.main(["--url", url, "submit", "--file", "failone:", "--worker", "3", "--wait", "--wait-limit", "60"]) == 1
+    assert "failed: worker task" in capsys.readouterr().out
+    assert job.main(["--url", url, "submit", "--file", "sleep:600", "--worker", "1"]) == 0
+    uid = capsys.readouterr().out.split()[1]
+    assert job.main(["--url", url, "status", uid]) == 0 and '"status": "running"' in capsys.readouterr().out
+    assert job.main(["--url", url, "cancel", uid]) == 0
+    assert job.main(["--url", url, "wait", uid, "--wait-limit", "60"]) == 1 and "cancelled" in capsys.readouterr().out
+    assert job.main(["--url", url, "status"]) == 0 and '"running": []' in capsys.readouterr().out.replace("\n", "").replace("  ", " ")
+    assert job.main(["--url", url, "submit", "--file", "sleep:1", "--worker", "0"]) == 1
+    assert "refused: HTTP 4" in capsys.readouterr().err
