@@ -79,6 +79,31 @@ class DisDeepService:
         ok = await loop.run_in_executor(None, self.handler.cancel, uid)
         return _json({"cancelled": ok}, 200 if ok else 404)
 
+    async def get_logs(self, request):
+        """``GET /v1/train/logs?uid=<uid>[&task=worker-0][&tail=200]`` -> ``{task name: text}``: what ``kubectl logs``
+        shows for the reference's pods.  The record names the job's tasks; the node agent keeps one file per task."""
+        uid, task, tail = request.query.get("uid"), request.query.get("task"), request.query.get("tail")
+        if not uid:
+            return _json({"error": "uid required"}, 400)
+        loop = asyncio.get_running_loop()
+        try:
+            res = await loop.run_in_executor(None, self.handler.logs, uid, task, int(tail) if tail else None)
+        except ValueError:
+            return _json({"error": "tail must be a number"}, 400)
+        if res is None:
+            return _json({"error": "unknown uid"}, 404)
+        return _json(res)
+
+    async def pod_log(self, request):
+        tail = request.query.get("tailLines")
+        loop = asyncio.get_running_loop()
+        try:
+            text = await loop.run_in_executor(None, self.cluster.read_namespaced_pod_log, request.match_info["name"],
+                                              request.match_info["ns"], int(tail) if tail else None)
+        except ApiException as e:
+            return _json({"error": e.reason}, e.status)
+        return _json({"log": text})
+
     # -- node agent API (k8s-shaped) -------------------------------------------
     async def _call(self, fn, *args):
         loop = asyncio.get_running_loop()
@@ -125,6 +150,7 @@ class DisDeepService:
         app.router.add_get("/v1/train", self.get_train)
         app.router.add_post("/v1/train", self.post_train)
         app.router.add_delete("/v1/train", self.delete_train)
+        app.router.add_get("/v1/train/logs", self.get_logs)
         app.router.add_get("/healthz", self.healthz)
         if self.cluster is not None and isinstance(self.cluster, LocalCluster):
             app.router.add_post("/api/v1/namespaces/{ns}/services", self.svc_create)
@@ -133,6 +159,7 @@ class DisDeepService:
             app.router.add_get("/apis/batch/v1/namespaces/{ns}/jobs", self.job_list)
             app.router.add_get("/apis/batch/v1/namespaces/{ns}/jobs/{name}", self.job_read)
             app.router.add_delete("/apis/batch/v1/namespaces/{ns}/jobs/{name}", self.job_delete)
+            app.router.add_get("/api/v1/namespaces/{ns}/pods/{name}/log", self.pod_log)
         return app
 
     # -- lifecycle ---------------------------------------------------------------

@@ -823,6 +823,23 @@ class LocalCluster:
                 raise ApiException(404, "job %s not found" % name)
             return AttrDict.wrap(self._snapshot(t))
 
+    def read_namespaced_pod_log(self, name, namespace=None, tail_lines=None, limit_bytes=4 << 20):
+        """``kubectl logs``: the task's stdout + stderr (one file per task under ``launcher.log_dir``; it outlives the
+        task, so the log of a reaped or failed task is still there).  ``tail_lines``: the last N lines only."""
+        if os.sep in name or name.startswith("."):
+            raise ApiException(400, "bad task name %r" % name)
+        path = os.path.join(self._log_dir, name + ".log")
+        if not os.path.isfile(path):
+            raise ApiException(404, "no log for task %s" % name)
+        size = os.path.getsize(path)
+        with open(path, "rb") as f:
+            if size > limit_bytes:
+                f.seek(size - limit_bytes)
+            text = f.read().decode(errors="replace")
+        if tail_lines is not None:
+            text = "".join(text.splitlines(True)[-max(0, int(tail_lines)):]) if int(tail_lines) > 0 else ""
+        return text
+
     def list_namespaced_job(self, namespace):
         with self._lock:
             return AttrDict.wrap({
@@ -1057,6 +1074,10 @@ class ClusterClient:
 
     def read_namespaced_job(self, name, namespace):
         return AttrDict.wrap(self._req("GET", "/apis/batch/v1/namespaces/%s/jobs/%s" % (namespace, name)))
+
+    def read_namespaced_pod_log(self, name, namespace=None, tail_lines=None):
+        q = "" if tail_lines is None else "?tailLines=%d" % int(tail_lines)
+        return self._req("GET", "/api/v1/namespaces/%s/pods/%s/log%s" % (namespace or "default", name, q))["log"]
 
     def list_namespaced_job(self, namespace):
         return AttrDict.wrap(self._req("GET", "/apis/batch/v1/namespaces/%s/jobs" % namespace))

@@ -155,6 +155,24 @@ class TrainHandler:
             rec["hbm_reclaim"] = [json.loads(r) for r in reclaim]
         return rec
 
+    def logs(self, uid, task=None, tail=None):
+        """``{task name: its log text}`` for the job's tasks (all, or those whose name contains ``task``, e.g.
+        ``worker-0``); ``None`` for an unknown uid.  A task whose log cannot be read maps to ``None``."""
+        raw = self.rc.get(uid)
+        if raw is None:
+            return None
+        rec = json.loads(raw)
+        names = [h.split(":")[0] for h in rec.get("ps", []) + rec.get("worker", [])]
+        out = {}
+        for n in names:
+            if task and ("-%s-" % task) not in n and task != n:
+                continue
+            try:
+                out[n] = self.cluster.read_namespaced_pod_log(n, manifest.namespace_for({}, self._cfg), tail)
+            except ApiException:
+                out[n] = None
+        return out
+
     def cancel(self, uid):
         """Enqueue the whole job for reaping (``DELETE /v1/train?uid=``)."""
         raw = self.rc.get(uid)

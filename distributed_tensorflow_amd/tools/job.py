@@ -6,6 +6,7 @@
     python -m distributed_tensorflow_amd.tools.job status [UID]
     python -m distributed_tensorflow_amd.tools.job wait UID
     python -m distributed_tensorflow_amd.tools.job cancel UID
+    python -m distributed_tensorflow_amd.tools.job logs UID [--task worker-0] [--tail 50]      # "kubectl logs"
 
 ``--url`` (or ``DTF_SERVICE_URL``) names the service, default ``http://127.0.0.1:12345``.  ``wait`` exits 0 when the job
 succeeded, 1 when it failed (the reason is printed), 2 when the time ran out."""
@@ -76,11 +77,14 @@ def main(argv=None):
     s.add_argument("--timeout", type=int, default=None, help="job deadline in seconds (activeDeadlineSeconds)")
     s.add_argument("--wait", action="store_true")
     s.add_argument("--wait-limit", type=float, default=0, help="seconds; 0 = no limit")
-    for name in ("status", "wait", "cancel"):
+    for name in ("status", "wait", "cancel", "logs"):
         p = sub.add_parser(name)
         p.add_argument("uid", nargs="?" if name == "status" else None)
         if name == "wait":
             p.add_argument("--wait-limit", type=float, default=0)
+        if name == "logs":
+            p.add_argument("--task", default=None, help="e.g. worker-0 or ps-0; default: every task of the job")
+            p.add_argument("--tail", type=int, default=None, help="last N lines of each")
     a = ap.parse_args(argv)
     if a.cmd == "submit":
         body = {"type": "tensorflow", "file": a.file, "detail": {"ps": a.ps, "worker": a.worker}}
@@ -105,6 +109,16 @@ def main(argv=None):
         return 0 if code == 200 else 1
     if a.cmd == "wait":
         return wait(a.url, a.uid, a.wait_limit)
+    if a.cmd == "logs":
+        q = "?uid=" + a.uid + ("&task=" + a.task if a.task else "") + ("&tail=%d" % a.tail if a.tail is not None else "")
+        code, res = call(a.url, "GET", "/v1/train/logs" + q)
+        if code != 200:
+            print("logs of %s: HTTP %d %s" % (a.uid, code, res), file=sys.stderr)
+            return 1
+        for n in sorted(res):
+            print("==> %s <==" % n)
+            print(res[n] if res[n] is not None else "(no log)", end="" if res[n] and res[n].endswith("\n") else "\n")
+        return 0
     code, rec = call(a.url, "DELETE", "/v1/train?uid=" + a.uid)
     print(json.dumps(rec))
     return 0 if code == 200 else 1

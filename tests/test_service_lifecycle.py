@@ -180,6 +180,7 @@ def test_command_line_client_submits_waits_reports_and_cancels(aio, capsys):
     assert job.main(["--url", url, "submit", "--file", "sleep:0.3", "--worker", "2", "--wait", "--wait-limit", "60"]) == 0
     out = capsys.readouterr().out
     assert "uid " in out and out.count("  task tf-") == 3 and "succeeded" in out
+    done_uid = out.split()[1]
     assert job.main(["--url", url, "submit", "--file", "failone:", "--worker", "3", "--wait", "--wait-limit", "60"]) == 1
     assert "failed: worker task" in capsys.readouterr().out
     assert job.main(["--url", url, "submit", "--file", "sleep:600", "--worker", "1"]) == 0
@@ -188,5 +189,12 @@ def test_command_line_client_submits_waits_reports_and_cancels(aio, capsys):
     assert job.main(["--url", url, "cancel", uid]) == 0
     assert job.main(["--url", url, "wait", uid, "--wait-limit", "60"]) == 1 and "cancelled" in capsys.readouterr().out
     assert job.main(["--url", url, "status"]) == 0 and '"running": []' in capsys.readouterr().out.replace("\n", "").replace("  ", " ")
+    # "kubectl logs" for a task that is long gone: the node agent keeps one file per task
+    assert job.main(["--url", url, "logs", done_uid, "--task", "worker-1", "--tail", "5"]) == 0
+    out = capsys.readouterr().out
+    assert out.count("==> tf-") == 1 and "worker-1-2 <==" in out and "fake task worker 1 sleep:0.3" in out
+    assert job.main(["--url", url, "logs", done_uid]) == 0 and capsys.readouterr().out.count("==> tf-") == 3
+    assert job.main(["--url", url, "logs", "no-such-uid"]) == 1
+    capsys.readouterr()
     assert job.main(["--url", url, "submit", "--file", "sleep:1", "--worker", "0"]) == 1
     assert "refused: HTTP 4" in capsys.readouterr().err
