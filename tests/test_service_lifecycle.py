@@ -198,3 +198,22 @@ def test_command_line_client_submits_waits_reports_and_cancels(aio, capsys):
     capsys.readouterr()
     assert job.main(["--url", url, "submit", "--file", "sleep:1", "--worker", "0"]) == 1
     assert "refused: HTTP 4" in capsys.readouterr().err
+
+
+def test_pod_log_through_the_k8s_shaped_api(aio):
+    """``read_namespaced_pod_log`` through the HTTP client the separate daemons use: whole log, tail, 404, bad name."""
+    from distributed_tensorflow_amd.service.launcher import ApiException, ClusterClient
+
+    a, port = aio
+    status, names = _post(port, {"file": "sleep:0.2", "detail": {"ps": 0, "worker": 1}})
+    assert status == 200
+    cc = ClusterClient("http://127.0.0.1:%d" % port)
+    assert _wait(lambda: "fake task worker 0" in (cc.read_namespaced_pod_log(names[0], "default") or ""), timeout=20)
+    assert cc.read_namespaced_pod_log(names[0], "default", tail_lines=1).count("\n") == 1
+    assert cc.read_namespaced_pod_log(names[0], "default", tail_lines=0) == ""
+    with pytest.raises(ApiException) as e:
+        cc.read_namespaced_pod_log("tf-nobody-worker-0-1", "default")
+    assert e.value.status == 404
+    with pytest.raises(ApiException) as e:
+        a.cluster.read_namespaced_pod_log("../secrets", "default")
+    assert e.value.status == 400
