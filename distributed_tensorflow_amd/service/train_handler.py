@@ -145,6 +145,12 @@ class TrainHandler:
         rec = json.loads(raw)
         metrics = rc.hgetall(uid + ":metrics")
         if metrics:
+            curve = metrics.pop("curve", None)
+            if curve:
+                try:
+                    rec["curve"] = {"columns": ["step", "loss", "items_per_sec"], "points": json.loads(curve)}
+                except ValueError:
+                    pass
             rec["metrics"] = metrics
             try:
                 rec["submit_to_step1_s"] = float(metrics["t_step1"]) - float(metrics["t_submit"])

@@ -204,6 +204,24 @@ class LoggingHook:
                 "  %.1f items/s" % (rate * self.items) if self.items else ""), flush=True)
 
 
+class SummaryHook:
+    """``tf.summary.scalar("loss", ...)`` + ``SummarySaverHook(save_steps=every_n)``: the chief appends the loss to
+    ``<checkpoint_dir>/scalars.jsonl`` (``train/summary.py``) every ``every_n`` steps (this synchronises the device)."""
+
+    def __init__(self, every_n=100, output_dir=None):
+        self.every_n, self.output_dir, self._log = int(every_n), output_dir, None
+
+    def begin(self, sess):
+        from .summary import ScalarLog
+
+        if sess.is_chief:
+            self._log = ScalarLog(self.output_dir or sess.checkpoint_dir)
+
+    def after_run(self, sess, loss):
+        if self._log is not None and sess.global_step % self.every_n == 0:
+            self._log.add(sess.global_step, loss=float(loss.detach().float().item()))
+
+
 class MonitoredTrainingSession:
     """``with MonitoredTrainingSession(model, optimizer, server=server, checkpoint_dir=export, hooks=[...]) as sess:``
     ``while not sess.should_stop(): sess.run(loss_fn(model, next(batches)))``.

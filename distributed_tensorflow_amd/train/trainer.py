@@ -134,7 +134,7 @@ def restore_checkpoint(model, ps, export, tf_names):
 
 
 def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=None, on_step=None,
-               items_per_step=None, start_step=0, graph=False, batches=None):
+               items_per_step=None, start_step=0, graph=False, batches=None, on_log=None):
     """Runs ``steps`` PS steps; returns (last_loss, seconds, steps_done).  ``graph=True``: after three eager steps
     the whole step (forward, backward, hook-launched PS pipeline incl. its collectives) is captured in one hipGraph
     and replayed -- the ~600 launches of a step then cost the host one call (GPU only).  ``graph="auto"``: capture, then
@@ -293,6 +293,8 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
             last = float(loss.detach().float().item())
             rate = (it + 1 - start_step) * (items_per_step or 0) / max(now - t0, 1e-9)
             print("[train] step %d loss %.5f  %.1f items/s" % (it + 1, last, rate), flush=True)
+            if on_log is not None:
+                on_log(it + 1, last, rate)
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     if loss is not None:
@@ -516,10 +518,17 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
                 print("[train] graph=%s ignored: a step with %s cannot be captured in one hipGraph" % (
                     "auto" if use_graph == "auto" else 1, why), flush=True)
             use_graph = False
+    on_log = None
+    if chief:
+        from .summary import ScalarLog
+
+        # the training curve: <export>/scalars.jsonl + a thinned copy in the job's metrics (train/summary.py)
+        curve = ScalarLog(export if do_ckpt else None, sink=metrics)
+        on_log = lambda step, loss, rate: curve.add(step, loss=loss, items_per_sec=rate)      # noqa: E731
     try:
         last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
                                    fault=fault, on_step=on_step, items_per_step=items, start_step=start_step,
-                                   graph=use_graph, batches=batches)
+                                   graph=use_graph, batches=batches, on_log=on_log)
     finally:
         if batches is not None:
             batches.close()

@@ -168,6 +168,24 @@ def test_train_loop_takes_a_new_batch_every_step():
     assert seen == [int(bs[i % 3][1].sum()) for i in range(7)]
 
 
+def test_scalar_log_appends_rows_and_thins_its_in_memory_copy(tmp_path):
+    from distributed_tensorflow_amd.train.summary import ScalarLog, read_scalars
+
+    seen = {}
+    log = ScalarLog(str(tmp_path / "x"), sink=lambda **kw: seen.update(kw), limit=16)
+    for i in range(1, 101):
+        log.add(i * 10, loss=1.0 / i, items_per_sec=100.0)
+    rows = read_scalars(str(tmp_path / "x"))
+    assert len(rows) == 100 and rows[-1] == {"step": 1000, "wall": rows[-1]["wall"], "loss": 0.01, "items_per_sec": 100.0}
+    pts = json.loads(seen["curve"])
+    assert len(pts) <= 16 and pts[-1][0] == 1000 and pts[0][0] == 10          # first and newest survive, the middle is thinned
+    assert [p[0] for p in pts] == sorted(p[0] for p in pts)
+    with open(str(tmp_path / "x" / "scalars.jsonl"), "a") as f:
+        f.write('{"step": 1010, "lo')                                           # a torn last line of a killed job
+    assert len(read_scalars(str(tmp_path / "x"))) == 100
+    assert ScalarLog("hdfs://nn/x").path is None and ScalarLog(None).add(1, loss=2.0)["loss"] == 2.0
+
+
 @pytest.mark.slow
 def test_rest_job_trains_mnist_from_idx_files_in_its_data_directory(tmp_path):
     """Config #1 with real input plumbing: POST a job whose ``data`` directory holds MNIST-format IDX files; two workers
@@ -186,7 +204,7 @@ def test_rest_job_trains_mnist_from_idx_files_in_its_data_directory(tmp_path):
     port = a.start(port=0)
     try:
         body = {"file": "builtin://mnist_mlp?steps=60&batch=64&placement=colocated&optimizer=momentum&lr=0.05&log_every=20",
-                "data": str(data), "detail": {"ps": 1, "worker": 2}}
+                "data": str(data), "export": str(tmp_path / "export"), "detail": {"ps": 1, "worker": 2}}
         req = urllib.request.Request("http://127.0.0.1:%d/v1/train" % port, data=json.dumps(body).encode(), method="POST")
         with urllib.request.urlopen(req, timeout=30) as r:
             names = json.loads(r.read().decode())
@@ -206,6 +224,15 @@ def test_rest_job_trains_mnist_from_idx_files_in_its_data_directory(tmp_path):
         assert "input: 4096 samples from" in logs and "(mnist), 32 steps per epoch" in logs, logs[-3000:]
         m = a.store.hgetall(uid + ":metrics")
         assert float(m["first_loss"]) > 1.5 and float(m["final_loss"]) < 0.5, m
+        # the training curve: in the export directory (the chief's scalars.jsonl) and in the job's status
+        from distributed_tensorflow_amd.train.summary import read_scalars
+
+        rows = read_scalars(str(tmp_path / "export"))
+        assert [r["step"] for r in rows] == [20, 40, 60] and rows[0]["loss"] > rows[-1]["loss"] and rows[-1]["items_per_sec"] > 0
+        with urllib.request.urlopen("http://127.0.0.1:%d/v1/train?uid=%s" % (port, uid), timeout=30) as r:
+            st = json.loads(r.read().decode())
+        assert st["curve"]["columns"] == ["step", "loss", "items_per_sec"] and [p[0] for p in st["curve"]["points"]] == [20, 40, 60]
+        assert "curve" not in st["metrics"]
     finally:
         a.stop()
 
