@@ -79,8 +79,10 @@ def _first(data_dir, names):
     return None
 
 
-def open_dataset(data_dir):
-    """-> :class:`ArrayDataset` for a directory in one of the layouts of the module docstring, else ``None``."""
+def open_dataset(data_dir, split="train"):
+    """-> :class:`ArrayDataset` for a directory in one of the layouts of the module docstring, else ``None``.
+    ``split``: which MNIST files to take when the directory holds both -- ``train`` (``train-*``) or ``test``
+    (``t10k-*``); a directory that holds only one of the two is read whatever ``split`` says."""
     if not data_dir or not os.path.isdir(data_dir):
         return None
     man = os.path.join(data_dir, "manifest.json")
@@ -90,10 +92,11 @@ def open_dataset(data_dir):
         names = [os.path.basename(str(n)) for n in m["fields"]]         # files of THIS directory only
         return ArrayDataset([np.load(os.path.join(data_dir, n), mmap_mode="r", allow_pickle=False) for n in names],
                             kind=str(m.get("kind", "generic")), source=man)
-    img = _first(data_dir, ("train-images-idx3-ubyte", "train-images-idx3-ubyte.gz", "train-images.idx3-ubyte"))
-    lab = _first(data_dir, ("train-labels-idx1-ubyte", "train-labels-idx1-ubyte.gz", "train-labels.idx1-ubyte"))
-    if img and lab:
-        return ArrayDataset([read_idx(img), read_idx(lab)], kind="mnist", source=img)
+    for pre in (("train", "t10k") if split != "test" else ("t10k", "train")):
+        img = _first(data_dir, tuple(pre + e for e in ("-images-idx3-ubyte", "-images-idx3-ubyte.gz", "-images.idx3-ubyte")))
+        lab = _first(data_dir, tuple(pre + e for e in ("-labels-idx1-ubyte", "-labels-idx1-ubyte.gz", "-labels.idx1-ubyte")))
+        if img and lab:
+            return ArrayDataset([read_idx(img), read_idx(lab)], kind="mnist", source=img)
     for xs, ys in (("images.npy", "labels.npy"), ("x.npy", "y.npy")):
         x, y = _first(data_dir, (xs,)), _first(data_dir, (ys,))
         if x and y:

@@ -118,10 +118,11 @@ def save_checkpoint(model, ps, export, step, tf_names, chief):
                         extra_sections=sections or None, extra_variables=variables or None)
 
 
-def restore_checkpoint(model, ps, export, tf_names):
+def restore_checkpoint(model, ps, export, tf_names, step=None):
     """Resume: dense PS state (any world size), replicated buffers, and the row-sharded embedding tables with
-    their accumulators (re-partitioned when the world size or the partition strategy changed).  Returns the step."""
-    rd = ckpt.restore_ps(ps, export, tf_names=tf_names)
+    their accumulators (re-partitioned when the world size or the partition strategy changed).  Returns the step
+    (``step=None``: the newest complete checkpoint)."""
+    rd = ckpt.restore_ps(ps, export, step=step, tf_names=tf_names)
     rep = rd.replicated()
     skip = tuple(n + "." for n, _ in _embedding_modules(model))
     with torch.no_grad():

@@ -182,3 +182,37 @@ def test_mnist_replica_on_the_gpu(tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "restored" in r.stdout and "global_step 150 on cuda:0" in r.stdout, r.stdout
     assert ckpt.latest_step(d) == 150
+
+
+def test_evaluate_tool_scores_a_checkpoint_on_held_out_data(tmp_path, capsys):
+    """Train on one set of synthetic digits through the session, evaluate the export directory on ANOTHER set with
+    ``tools.evaluate``: loss and accuracy of the restored model, an older step on request, a clear error without data."""
+    from distributed_tensorflow_amd.tools import evaluate as ev
+    from distributed_tensorflow_amd.train import data as D
+    from tests.test_data import _digits
+
+    x, y = _digits(2048, seed=3)
+    hx, hy = _digits(512, seed=99)
+    held = tmp_path / "held"
+    held.mkdir()
+    D.write_idx(str(held / "t10k-images-idx3-ubyte.gz"), hx)
+    D.write_idx(str(held / "t10k-labels-idx1-ubyte.gz"), hy)
+    ds = D.ArrayDataset([x, y], kind="mnist")
+    tf = D.transform_for(mnist_mlp, ds, "cpu")
+    stream = D.BatchStream(ds, 64, seed=0)
+    torch.manual_seed(0)
+    model = mnist_mlp.build()
+    d = str(tmp_path / "export")
+    with S.MonitoredTrainingSession(model, {"kind": "momentum", "lr": 0.05, "momentum": 0.9}, comm=Comm.single(),
+                                    checkpoint_dir=d, save_checkpoint_steps=10, hooks=[S.StopAtStepHook(last_step=150)],
+                                    tf_names=mnist_mlp.tf_variable_names(model), keep_checkpoints=0) as sess:
+        while not sess.should_stop():
+            sess.run(mnist_mlp.loss_fn(model, tf([torch.from_numpy(a) for a in next(stream)])))
+    assert ev.main(["--model", "mnist_mlp", "--export", d, "--data", str(held), "--batch", "128", "--device", "cpu"]) == 0
+    res = json.loads(capsys.readouterr().out)
+    assert res["step"] == 150 and res["samples"] == 512 and res["accuracy"] > 0.9 and res["loss"] < 0.5, res
+    assert ev.main(["--model", "mnist_mlp", "--export", d, "--data", str(held), "--step", "10", "--device", "cpu"]) == 0
+    early = json.loads(capsys.readouterr().out)
+    assert early["step"] == 10 and early["loss"] > 10 * res["loss"] and early["accuracy"] <= res["accuracy"], (early, res)
+    assert ev.main(["--model", "mnist_mlp", "--export", d, "--data", str(tmp_path / "nothing"), "--device", "cpu"]) == 1
+    assert "no dataset under" in capsys.readouterr().err
