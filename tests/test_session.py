@@ -216,3 +216,51 @@ def test_evaluate_tool_scores_a_checkpoint_on_held_out_data(tmp_path, capsys):
     assert early["step"] == 10 and early["loss"] > 10 * res["loss"] and early["accuracy"] <= res["accuracy"], (early, res)
     assert ev.main(["--model", "mnist_mlp", "--export", d, "--data", str(tmp_path / "nothing"), "--device", "cpu"]) == 1
     assert "no dataset under" in capsys.readouterr().err
+
+
+@pytest.mark.gpu
+def test_evaluate_restores_resnet50_on_the_gpu_exactly(tmp_path):
+    """ResNet-50 (channels-last, bf16, own kernels) trained a few steps on the device, checkpointed, then scored by
+    ``tools.evaluate`` in eval mode on an images.npy directory: the loss equals what the LIVE model gives on the same
+    rows -- every variable and every BatchNorm moving statistic came back."""
+    import types
+
+    import numpy as np
+
+    from distributed_tensorflow_amd.models import get_model_module
+    from distributed_tensorflow_amd.parallel.ps_runtime import ShardedPS
+    from distributed_tensorflow_amd.tools import evaluate as ev
+    from distributed_tensorflow_amd.train import data as D
+    from distributed_tensorflow_amd.train.trainer import prepare_model, save_checkpoint
+
+    dev = torch.device("cuda", 0)
+    mod = get_model_module("resnet50")
+    torch.manual_seed(0)
+    model = prepare_model(mod, types.SimpleNamespace(extra={}), dev, None)
+    ps = ShardedPS(list(model.named_parameters()), Comm(0, 1, dev), mod.default_optimizer())
+    batch = mod.synthetic_batch(32, device=dev, seed=5, image_size=96)
+    for _ in range(6):
+        mod.loss_fn(model, batch).backward()
+        ps.step()
+    d = str(tmp_path / "export")
+    save_checkpoint(model, ps, d, ps.global_step, mod.tf_variable_names(model), True)
+    rng = np.random.default_rng(0)
+    data = tmp_path / "val"
+    data.mkdir()
+    img = rng.integers(0, 256, (64, 96, 96, 3), dtype=np.uint8)
+    lab = rng.integers(0, 1000, 64).astype(np.int64)
+    np.save(str(data / "images.npy"), img)
+    np.save(str(data / "labels.npy"), lab)
+    res = ev.evaluate("resnet50", d, str(data), batch=32, device="cuda:0")
+    assert res["step"] == 6 and res["samples"] == 64 and 0.0 <= res["accuracy"] <= 1.0
+    ds = D.open_dataset(str(data))
+    tf = D.transform_for(mod, ds, dev)
+    model.eval()
+    want = 0.0
+    with torch.no_grad():
+        for lo in (0, 32):
+            want += float(mod.loss_fn(model, tf([torch.from_numpy(img[lo:lo + 32]).to(dev), torch.from_numpy(lab[lo:lo + 32]).to(dev)])).double())
+    # (six steps on one batch leave the moving statistics far from the batch's: the eval-mode loss is huge, which makes it
+    # a sensitive probe -- one wrong statistic or variable moves it by orders of magnitude; the tolerance covers the
+    # run-to-run rounding of small-batch forward passes in the default mode)
+    assert res["loss"] == pytest.approx(want / 2, rel=1e-4), (res, want / 2)
