@@ -184,6 +184,9 @@ def _main_staged(t_start, argv, job_name, task_index, ps_csv, worker_csv, file_f
     os.environ.update({
         "DTF_JOB_NAME": job_name, "DTF_TASK_INDEX": str(task_index), "DTF_JOB_UID": uid,
         "DTF_PS_HOSTS": ps_csv, "DTF_WORKER_HOSTS": worker_csv,
+        # what Estimator-era TF scripts read instead of flags (train/session.py: ClusterSpec.from_tf_config)
+        "TF_CONFIG": json.dumps({"cluster": {"ps": ps_hosts, "worker": worker_hosts},
+                                 "task": {"type": job_name, "index": task_index}}),
     })
 
     if kind == "script":

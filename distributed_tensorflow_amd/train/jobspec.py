@@ -8,7 +8,7 @@ fetches ``file`` from HDFS and runs it.  Here ``file`` is either
   (query keys override the ``[train]`` config section), or
 * a path to a user python script, run with the cluster description in the
   environment (``DTF_JOB_NAME``, ``DTF_TASK_INDEX``, ``DTF_PS_HOSTS``,
-  ``DTF_WORKER_HOSTS``, ``RANK``/``WORLD_SIZE``/``MASTER_ADDR``/``MASTER_PORT``)
+  ``DTF_WORKER_HOSTS``, ``TF_CONFIG``, ``RANK``/``WORLD_SIZE``/``MASTER_ADDR``/``MASTER_PORT``)
   and the same nine arguments in ``sys.argv``.
 """
 from __future__ import annotations

@@ -61,6 +61,16 @@ class ClusterSpec:
     def from_env(cls):
         return cls.from_lists(os.environ.get("DTF_PS_HOSTS", ""), os.environ.get("DTF_WORKER_HOSTS", ""))
 
+    @classmethod
+    def from_tf_config(cls, value=None):
+        """-> ``(ClusterSpec, job_name, task_index)`` from a ``TF_CONFIG`` document (default: the environment's; the
+        service sets it for every task): ``{"cluster": {"ps": [...], "worker": [...]}, "task": {"type", "index"}}``."""
+        import json
+
+        doc = json.loads(value if value is not None else os.environ.get("TF_CONFIG", "{}") or "{}")
+        task = doc.get("task") or {}
+        return cls(doc.get("cluster") or {}), str(task.get("type", "worker")), int(task.get("index", 0))
+
     @property
     def jobs(self):
         return sorted(self._jobs)

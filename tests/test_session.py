@@ -33,6 +33,10 @@ def test_cluster_spec_and_placement():
     assert cs.jobs == ["ps", "worker"] and cs.num_tasks("worker") == 2 and cs.task_address("worker", 1) == "c:2222"
     assert S.ClusterSpec(cs.as_dict()).as_dict() == {"ps": ["a:2222"], "worker": ["b:2222", "c:2222"]}
     assert S.ClusterSpec({"worker": {0: "x:1", 1: "y:2"}}).job_tasks("worker") == ["x:1", "y:2"]
+    cs2, job, idx = S.ClusterSpec.from_tf_config('{"cluster": {"ps": ["a:2222"], "worker": ["b:2222", "c:2222"]}, '
+                                                 '"task": {"type": "worker", "index": 1}}')
+    assert cs2.as_dict() == cs.as_dict() and (job, idx) == ("worker", 1)
+    assert S.ClusterSpec.from_tf_config("{}")[1:] == ("worker", 0)
     assert S.replica_device_setter(cluster=cs).num_shards == 1
     assert S.replica_device_setter(ps_tasks=4).num_shards == 4
     assert S.replica_device_setter().num_shards is None
@@ -264,3 +268,48 @@ def test_evaluate_restores_resnet50_on_the_gpu_exactly(tmp_path):
     # a sensitive probe -- one wrong statistic or variable moves it by orders of magnitude; the tolerance covers the
     # run-to-run rounding of small-batch forward passes in the default mode)
     assert res["loss"] == pytest.approx(want / 2, rel=1e-4), (res, want / 2)
+
+
+@pytest.mark.slow
+def test_tasks_of_a_script_job_get_tf_config(tmp_path):
+    """Estimator-era scripts read ``TF_CONFIG`` instead of flags: every task of a job gets the document (cluster with the
+    job's two host lists, its own type and index), and ``ClusterSpec.from_tf_config()`` reads it."""
+    from distributed_tensorflow_amd.service.disTf import AllInOne
+    from distributed_tensorflow_amd.utils.config import ApiConfig
+    from distributed_tensorflow_amd.utils.naming import parse_task_name
+
+    script = tmp_path / "dump_tf_config.py"
+    script.write_text(
+        "import json, os, sys\n"
+        "from distributed_tensorflow_amd.train.session import ClusterSpec\n"
+        "cs, job, idx = ClusterSpec.from_tf_config()\n"
+        "out = sys.argv[7]\n"
+        "os.makedirs(out, exist_ok=True)\n"
+        "json.dump({'cluster': cs.as_dict(), 'job': job, 'index': idx, 'argv': sys.argv[1:5]},\n"
+        "          open(os.path.join(out, 'task-%d.json' % idx), 'w'))\n")
+    ApiConfig.override("launcher", "grace_seconds", "1")
+    a = AllInOne(gpus=[], log_dir=str(tmp_path / "tasks"))
+    port = a.start(port=0)
+    try:
+        export = str(tmp_path / "export")
+        body = {"file": str(script), "export": export, "detail": {"ps": 1, "worker": 2}}
+        req = urllib.request.Request("http://127.0.0.1:%d/v1/train" % port, data=json.dumps(body).encode(), method="POST")
+        with urllib.request.urlopen(req, timeout=30) as r:
+            names = json.loads(r.read().decode())
+        uid = parse_task_name(names[0])[0]
+        t0 = time.time()
+        rec = {}
+        while time.time() - t0 < 120:
+            rec = json.loads(a.store.get(uid))
+            if "t_cleaned" in rec:
+                break
+            time.sleep(0.2)
+        assert rec.get("status") == "succeeded", rec
+        for i in (0, 1):
+            t = json.load(open(os.path.join(export, "task-%d.json" % i)))
+            assert t["job"] == "worker" and t["index"] == i == int(t["argv"][1])
+            assert [h.split(":")[0] for h in t["cluster"]["worker"]] == names[1:]
+            assert [h.split(":")[0] for h in t["cluster"]["ps"]] == names[:1]
+            assert ",".join(t["cluster"]["worker"]) == t["argv"][3]
+    finally:
+        a.stop()
