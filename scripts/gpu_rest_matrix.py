@@ -129,6 +129,66 @@ if len(sys.argv) > 1 and sys.argv[1] == "edges":
     aio.stop()
     print("edges:", "all as intended" if ok else "SOMETHING WRONG", "(%.0f s)" % (time.time() - t0))
     sys.exit(0 if ok else 1)
+if len(sys.argv) > 1 and sys.argv[1] == "burst":
+    # 24 jobs POSTed from 8 threads at once onto one device: each is a gang of (ps, worker), all must run one after the
+    # other, none may be lost, the device and every reservation must be back at the end
+    import threading
+
+    N = 24
+    uids, errs, lock = [], [], threading.Lock()
+
+    def submit(i):
+        body = {"type": "tensorflow", "data": "/synthetic", "resource": {"cpu": 8, "mem": "32g", "gpu": 1},
+                "detail": {"ps": 1, "worker": 1},
+                "file": (R + "steps=30") if i % 3 else "builtin://mnist_mlp?batch=64&steps=200&log_every=100"}
+        try:
+            u = parse_task_name(http(port, "POST", "/v1/train", body)[0])[0]
+            with lock:
+                uids.append(u)
+        except Exception as e:      # noqa: BLE001
+            with lock:
+                errs.append(repr(e))
+
+    t0 = time.time()
+    ths = [threading.Thread(target=submit, args=(i,)) for i in range(N)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    print("%d jobs accepted in %.2f s (%d refused: %s)" % (len(uids), time.time() - t0, len(errs), errs[:2]), flush=True)
+    peak_running = 0
+    t_say = time.time()
+    while time.time() - t0 < 600:
+        st = http(port, "GET", "/v1/train")
+        ns = ApiConfig().get("namespace", "tensorflow")
+        running = sum(1 for j in aio.cluster.list_namespaced_job(ns)["items"]
+                      if j["status"]["phase"] == "Running" and "-worker-" in j["metadata"]["name"])
+        peak_running = max(peak_running, running)
+        if not st["running"]:
+            break
+        if time.time() - t_say > 20:
+            t_say = time.time()
+            print("   ... %d running, %d succeeded, %d failed after %.0f s" % (
+                len(st["running"]), len(st["succeeded"]), len(st["failed"]), time.time() - t0), flush=True)
+        time.sleep(0.25)
+    st = http(port, "GET", "/v1/train")
+    recs = [http(port, "GET", "/v1/train?uid=" + u) for u in uids]
+    t_f = time.time()
+    while aio.cluster.free_gpus() != ([] if CPU else [0]) and time.time() - t_f < 30:
+        time.sleep(0.1)
+    firsts = sorted(float(r["metrics"]["t_step1"]) for r in recs if "t_step1" in r.get("metrics", {}))
+    gaps = [b - a for a, b in zip(firsts, firsts[1:])]
+    ok = (len(uids) == N and len(st["succeeded"]) == N and not st["failed"] and not st["running"]
+          and aio.cluster.free_gpus() == ([] if CPU else [0]) and not aio.cluster._gangs and (CPU or peak_running == 1))
+    print("burst of %d: %d succeeded, %d failed, %d still running after %.0f s; worker tasks running at once: at most %d; "
+          "first steps %.1f s apart on average; free devices %s, reservations %s, torn-down gangs %s" % (
+              N, len(st["succeeded"]), len(st["failed"]), len(st["running"]), time.time() - t0, peak_running,
+              sum(gaps) / max(1, len(gaps)), aio.cluster.free_gpus(), aio.cluster._gangs, len(aio.cluster._gang_broken)), flush=True)
+    rcl = [x.get("reclaimed") for r in recs for x in (r.get("hbm_reclaim") or [])]
+    print("HBM reclaim reports: %d, all reclaimed: %s" % (len(rcl), all(rcl)), flush=True)
+    aio.stop()
+    print("burst:", "all as intended" if ok else "SOMETHING WRONG")
+    sys.exit(0 if ok else 1)
 out = []
 for name, spec in jobs:
     body = {"type": "tensorflow", "data": "/synthetic", "resource": {"cpu": 8, "mem": "32g", "gpu": 1}, "detail": {"ps": 1, "worker": 1}}
