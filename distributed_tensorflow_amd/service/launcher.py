@@ -400,6 +400,8 @@ class LocalCluster:
         self._gangs = {}            # job uid -> devices set aside for its tasks that have not started yet
         self._gang_broken = set()   # jobs being torn down: no reservation any more
         self._log_dir = log_dir or cfg.get("launcher", "log_dir", "logs/tasks")
+        # notes about running tasks (reap_orphans): NEXT TO the log directory, which holds nothing but task logs
+        self._run_dir = os.path.abspath(self._log_dir).rstrip(os.sep) + ".running"
         self._python = python or sys.executable
         self._extra_env = dict(extra_env or {})
         self._grace = cfg.getfloat("launcher", "grace_seconds", 5)
@@ -424,6 +426,12 @@ class LocalCluster:
         # which in a long-lived service grows without bound: a finished Job is deleted ``ttlSecondsAfterFinished``
         # (Job spec, the k8s field) or ``finished_job_ttl_seconds`` (config default for all Jobs) after it ended; 0 = keep
         self._finished_ttl = cfg.getfloat("launcher", "finished_job_ttl_seconds", 0.0)
+        # tasks a previous service instance left behind hold devices this instance is about to hand out
+        try:
+            self.orphans_reaped = self.reap_orphans() if cfg.getboolean("launcher", "reap_orphans", True) else []
+        except Exception:       # noqa: BLE001 -- never a reason not to start
+            log.exception("orphan sweep failed")
+            self.orphans_reaped = []
         # warm rank pools: only for the framework's own entry module (a custom image starts cold)
         n_warm = cfg.getint("launcher", "warm_pool", 0)
         self._root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -684,6 +692,7 @@ class LocalCluster:
                 logf.close()
         t.status.update(active=1, phase="Running", startTime=time.time())
         self._emit("MODIFIED", t)
+        self._register_running(t)
         threading.Thread(target=self._reap, args=(t,), name="wait-" + t.name, daemon=True).start()
         deadline = t.body["spec"].get("activeDeadlineSeconds")
         if deadline and not t.name.split("-")[-3] == "ps":
@@ -718,6 +727,7 @@ class LocalCluster:
                     for d in t.hbm_during:
                         d["after_first_step"] = seen
         rc = t.proc.wait()
+        self._unregister_running(t)
         self._sweep_stage(t)
         with self._lock:
             t.exit_code = rc
@@ -737,6 +747,87 @@ class LocalCluster:
                 self._schedule()
                 self._respawn_hot(t)
         self._arm_ttl(t)
+
+    # ------------------------------------------------------------ tasks that outlive the service
+    # A task is its own session (its process group is what delete kills), so it survives a service that is killed --
+    # and would keep its device while the restarted service, which knows nothing of it, hands the same device to the
+    # next job.  Every running task therefore leaves a note under <log_dir>.running (pid + the kernel's start time of
+    # that pid, so a recycled pid is never mistaken for it); a starting service kills what the notes of a DEAD service
+    # still point to.  Notes of a service that is alive (two services sharing a log directory) are left alone.
+    @staticmethod
+    def _proc_start(pid):
+        try:
+            with open("/proc/%d/stat" % pid) as f:
+                return f.read().rsplit(")", 1)[1].split()[19]       # field 22: starttime in clock ticks
+        except (OSError, IndexError):
+            return None
+
+    def _register_running(self, t):
+        try:
+            d = self._run_dir
+            os.makedirs(d, exist_ok=True)
+            note = {"name": t.name, "pid": t.proc.pid, "start": self._proc_start(t.proc.pid), "gpus": list(t.gpus),
+                    "owner": os.getpid(), "owner_start": self._proc_start(os.getpid())}
+            tmp = os.path.join(d, t.name + ".json.tmp")
+            with open(tmp, "w") as f:
+                json.dump(note, f)
+            os.replace(tmp, os.path.join(d, t.name + ".json"))
+        except OSError:
+            pass
+
+    def _unregister_running(self, t):
+        try:
+            os.unlink(os.path.join(self._run_dir, t.name + ".json"))
+        except OSError:
+            pass
+
+    def reap_orphans(self):
+        """Kill the tasks a previous, dead service instance left running; returns their names."""
+        d = self._run_dir
+        killed = []
+        for f in sorted(os.listdir(d)) if os.path.isdir(d) else []:
+            if not f.endswith(".json"):
+                continue
+            path = os.path.join(d, f)
+            try:
+                with open(path) as fh:
+                    note = json.load(fh)
+                pid, owner = int(note["pid"]), int(note.get("owner", 0))
+            except (OSError, ValueError, KeyError, TypeError):
+                continue
+            if owner and owner != os.getpid() and self._proc_start(owner) is not None \
+                    and self._proc_start(owner) == note.get("owner_start"):
+                log.warning("task %s belongs to a live service (pid %d) that shares %s: left alone", note.get("name"), owner,
+                            self._log_dir)
+                continue
+            if owner == os.getpid() and self._proc_start(owner) == note.get("owner_start"):
+                continue            # a second LocalCluster of this very process
+            if note.get("start") is not None and self._proc_start(pid) == note["start"]:
+                log.warning("task %s (pid %d, devices %s) outlived the service that started it: killing it",
+                            note.get("name"), pid, note.get("gpus"))
+                for sig, wait_s in ((signal.SIGTERM, self._grace), (signal.SIGKILL, self._kill_wait)):
+                    try:
+                        os.killpg(pid, sig)
+                    except (ProcessLookupError, PermissionError):
+                        try:
+                            os.kill(pid, sig)
+                        except (ProcessLookupError, PermissionError):
+                            break
+                    t_end = time.time() + wait_s
+                    while time.time() < t_end and self._proc_start(pid) == note["start"]:
+                        try:
+                            os.waitpid(pid, os.WNOHANG)       # our own child in tests; a stranger's in production
+                        except (ChildProcessError, OSError):
+                            pass
+                        time.sleep(0.05)
+                    if self._proc_start(pid) != note["start"]:
+                        break
+                killed.append(note.get("name"))
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return killed
 
     def _arm_ttl(self, t):
         ttl = (t.body.get("spec") or {}).get("ttlSecondsAfterFinished")

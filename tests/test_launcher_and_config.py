@@ -523,3 +523,64 @@ def test_finished_jobs_are_garbage_collected_after_their_ttl(cluster):
     cluster._finished_ttl = 0.2
     late = cluster.create_namespaced_job("default", _job(3, 4, 0, "exit:0"))["metadata"]["name"]
     assert _wait(lambda: late not in names(), timeout=10) and kept in names()
+
+
+def test_tasks_that_outlived_a_killed_service_are_reaped_by_the_next_one(tmp_path):
+    """A service process that is SIGKILLed leaves its tasks running (each is its own session) on devices the next
+    service instance would hand out again.  Every running task leaves a note (pid + kernel start time); a starting
+    LocalCluster kills what the notes of a DEAD owner point to, leaves the tasks of a LIVE owner alone, and is not
+    fooled by a recycled pid."""
+    import signal
+    import subprocess
+    import sys
+    import textwrap
+
+    logs = str(tmp_path / "tasks")
+    svc = textwrap.dedent("""
+        import sys, time
+        sys.path.insert(0, %r)
+        from distributed_tensorflow_amd.utils.config import ApiConfig
+        ApiConfig.override("image", "tensorflow", "tests.fake_task")
+        ApiConfig.override("launcher", "verify_reclaim", "0")
+        from distributed_tensorflow_amd.service import manifest
+        from distributed_tensorflow_amd.service.launcher import LocalCluster
+        c = LocalCluster(gpus=[0], log_dir=%r, extra_env={"PYTHONPATH": %r})
+        info = {"file": "sleep:600", "resource": {"gpu": 1}, "detail": {"ps": 0, "worker": 1}}
+        j = c.create_namespaced_job("default", manifest.gen_job("aaaaaaaa-0000-11f1-8000-000000000001", "worker", 0, 1, info, "", ""))
+        print("task", c._jobs[("default", j["metadata"]["name"])].proc.pid, flush=True)
+        time.sleep(600)
+    """) % (ROOT, logs, ROOT)
+    p = subprocess.Popen([sys.executable, "-c", svc], stdout=subprocess.PIPE, text=True)
+    try:
+        line = p.stdout.readline()
+        assert line.startswith("task "), line
+        task_pid = int(line.split()[1])
+        ApiConfig.override("image", "tensorflow", "tests.fake_task")
+        ApiConfig.override("launcher", "verify_reclaim", "0")
+        ApiConfig.override("launcher", "grace_seconds", "0.3")
+        # the first service is alive: a second one sharing the directory must not touch its task
+        c1 = LocalCluster(gpus=[0], log_dir=logs)
+        assert c1.orphans_reaped == [] and LocalCluster._proc_start(task_pid) is not None
+        c1.shutdown()
+        os.kill(p.pid, signal.SIGKILL)
+        p.wait()
+        assert LocalCluster._proc_start(task_pid) is not None          # the task outlived its service
+        c2 = LocalCluster(gpus=[0], log_dir=logs)
+        assert c2.orphans_reaped == ["tf-aaaaaaaa-0000-11f1-8000-000000000001-worker-0-1"]
+        assert _wait(lambda: LocalCluster._proc_start(task_pid) is None, 5)
+        assert os.listdir(logs + ".running") == []
+        c2.shutdown()
+        # a note whose pid now belongs to somebody else (start time differs): removed, nobody is killed
+        with open(os.path.join(logs + ".running", "tf-x-worker-0-1.json"), "w") as f:
+            json.dump({"name": "tf-x-worker-0-1", "pid": os.getpid(), "start": "1", "gpus": [0], "owner": 1, "owner_start": "0"}, f)
+        c3 = LocalCluster(gpus=[0], log_dir=logs)
+        assert c3.orphans_reaped == [] and os.listdir(logs + ".running") == []
+        c3.shutdown()
+    finally:
+        if p.poll() is None:
+            p.kill()
+        try:
+            os.killpg(task_pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError, UnboundLocalError):
+            pass
+        ApiConfig.override("launcher", "verify_reclaim", "1")
