@@ -174,6 +174,7 @@ class DisDeepService:
         """Blocking, like the reference's ``IOLoop.current().start()``."""
         host = self.config.get("service", "host", "127.0.0.1")
         port = self.config.getint("service", "port")
+        self.reconcile()
         loop = asyncio.new_event_loop()
         asyncio.set_event_loop(loop)
         loop.run_until_complete(self._serve(host, port))
@@ -186,8 +187,18 @@ class DisDeepService:
         finally:
             loop.run_until_complete(self._runner.cleanup())
 
+    def reconcile(self):
+        """Before serving: records left "running" by a previous instance of this service (external store)."""
+        if isinstance(self.cluster, LocalCluster):
+            try:
+                return self.handler.reconcile()
+            except Exception:       # noqa: BLE001 -- a store that is not up yet must not keep the service down
+                log.exception("reconcile failed")
+        return []
+
     def start_background(self, host=None, port=None):
         """Serve from a daemon thread; returns the bound port (tests, bench)."""
+        self.reconcile()
         host = host or self.config.get("service", "host", "127.0.0.1")
         port = self.config.getint("service", "port") if port is None else port
         ready = threading.Event()

@@ -161,6 +161,42 @@ class TrainHandler:
             rec["hbm_reclaim"] = [json.loads(r) for r in reclaim]
         return rec
 
+    def reconcile(self):
+        """Called by a starting service that hosts the node agent: a record that still says "running" although none
+        of its tasks exists belongs to a job of a previous service instance (killed with it, or reaped as orphans by
+        ``LocalCluster.reap_orphans``) -- with an external store it would say "running" for ever.  Returns the uids
+        it marked failed."""
+        rc, cfg = self.rc, self._cfg
+        ns = manifest.namespace_for({}, cfg)
+        lost = []
+        for uid in sorted(rc.smembers(cfg.get("redis", "running_set")) or []):
+            uid = uid.decode() if isinstance(uid, bytes) else str(uid)
+            raw = rc.get(uid)
+            if raw is None:
+                rc.srem(cfg.get("redis", "running_set"), uid)
+                continue
+            rec = json.loads(raw)
+            alive = False
+            for n in [h.split(":")[0] for h in rec.get("ps", []) + rec.get("worker", [])]:
+                try:
+                    self.cluster.read_namespaced_job(n, ns)
+                    alive = True
+                    break
+                except ApiException:
+                    pass
+            if alive:
+                continue
+            now = time.time()
+            rec.update(status="failed", reason="the service restarted while the job was running: its tasks are gone",
+                       t_failed=now, t_cleaned=now)
+            rc.set(uid, json.dumps(rec))
+            rc.srem(cfg.get("redis", "running_set"), uid)
+            rc.sadd(cfg.get("redis", "failed_set", "failed_uids"), uid)
+            lost.append(uid)
+        if lost:
+            log.warning("jobs of a previous service instance marked failed: %s", ", ".join(lost))
+        return lost
+
     def logs(self, uid, task=None, tail=None):
         """``{task name: its log text}`` for the job's tasks (all, or those whose name contains ``task``, e.g.
         ``worker-0``); ``None`` for an unknown uid.  A task whose log cannot be read maps to ``None``."""

@@ -217,3 +217,30 @@ def test_pod_log_through_the_k8s_shaped_api(aio):
     with pytest.raises(ApiException) as e:
         a.cluster.read_namespaced_pod_log("../secrets", "default")
     assert e.value.status == 400
+
+
+def test_records_left_running_by_a_previous_service_instance_are_closed(tmp_path):
+    """External store, service restarted: a record that says "running" while none of its tasks exists is marked failed
+    with that reason when the new instance starts; a record whose tasks DO exist is left alone."""
+    ApiConfig.override("image", "tensorflow", "tests.fake_task")
+    ApiConfig.override("launcher", "grace_seconds", "0.5")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = AllInOne(gpus=[], log_dir=str(tmp_path / "tasks"), extra_env={"PYTHONPATH": root})
+    try:
+        cfg = ApiConfig()
+        ghost = "99999999-0000-11f1-8000-00000000dead"
+        a.store.set(ghost, json.dumps({"ps": ["tf-%s-ps-0-1:2222" % ghost], "worker": ["tf-%s-worker-0-1:2222" % ghost],
+                                       "status": "running"}))
+        a.store.sadd(cfg.get("redis", "running_set"), ghost)
+        port = a.start(port=0)
+        rec = json.loads(a.store.get(ghost))
+        assert rec["status"] == "failed" and "service restarted" in rec["reason"] and "t_cleaned" in rec
+        status, names = _post(port, {"file": "sleep:30", "detail": {"ps": 1, "worker": 1}})
+        live = parse_task_name(names[0])[0]
+        assert a.service.reconcile() == []                       # a job whose tasks exist is not touched
+        assert json.loads(a.store.get(live))["status"] == "running"
+        with urllib.request.urlopen("http://127.0.0.1:%d/v1/train" % port, timeout=30) as r:
+            st = json.loads(r.read().decode())
+        assert st["failed"] == [ghost] and st["running"] == [live]
+    finally:
+        a.stop()
