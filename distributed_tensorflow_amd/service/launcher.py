@@ -313,13 +313,18 @@ class _HotPool:
             if not line.startswith(b"WARM"):
                 raise RuntimeError("hot worker for GPU %d did not come up" % g)
         except Exception:       # noqa: BLE001 -- no hot worker just means a colder start
-            log.exception("hot worker for GPU %d failed to start", g)
-            if p is not None:
-                p.kill()
             with self._lock:
                 cur = self._procs.get(g)
-                if cur is not None and cur[2] == gen:
+                mine = cur is not None and cur[2] == gen
+                if mine:
                     self._procs.pop(g, None)
+            if mine and not self._closed:
+                log.exception("hot worker for GPU %d failed to start", g)
+            else:
+                # take() / close() stopped it while it was coming up: a task got the device first (a burst of jobs)
+                log.info("hot worker for GPU %d was stopped while starting: a task took the device", g)
+            if p is not None:
+                p.kill()
             return
         with self._lock:
             cur = self._procs.get(g)

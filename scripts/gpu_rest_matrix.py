@@ -17,6 +17,9 @@ def http(port, method, path, body=None):
 
 
 ApiConfig.override("launcher", "grace_seconds", "3")
+if os.environ.get("DTF_MATRIX_HOT") == "1":        # GPU-hot warm ranks: one per free device, model hint from the last job
+    ApiConfig.override("launcher", "warm_gpu_pool", "1")
+    ApiConfig.override("launcher", "warm_model", "auto")
 logs = os.path.join("gpurun_out", "rest_matrix_tasks")
 CPU = os.environ.get("DTF_MATRIX_CPU") == "1"          # rehearsal of the script itself on a box without a device
 aio = AllInOne(gpus=[] if CPU else [0], log_dir=logs)
