@@ -584,3 +584,13 @@ def test_tasks_that_outlived_a_killed_service_are_reaped_by_the_next_one(tmp_pat
         except (ProcessLookupError, PermissionError, UnboundLocalError):
             pass
         ApiConfig.override("launcher", "verify_reclaim", "1")
+
+
+def test_package_front_door_lists_and_dispatches_commands(capsys):
+    from distributed_tensorflow_amd import __main__ as front
+
+    assert front.main([]) == 0
+    out = capsys.readouterr().out
+    assert all(w in out for w in ("serve", "cleaner | reaper", "job submit", "inspect", "evaluate", "build"))
+    assert front.main(["nope"]) == 2 and "unknown command 'nope'" in capsys.readouterr().err
+    assert front.main(["inspect", "/nonexistent-export"]) == 1 and "no checkpoint under" in capsys.readouterr().err
