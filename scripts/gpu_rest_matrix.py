@@ -67,6 +67,32 @@ if len(sys.argv) > 1 and sys.argv[1] == "odd":
         ("dataset smaller than a batch", {"file": "builtin://resnet50?batch=1024&steps=4", "data": data}),
         ("unknown model option", {"file": R + "steps=6&no_such_option=1"}),
         ("inception_v3 aux_logits", {"file": "builtin://inception_v3?batch=16&steps=6&aux_logits=1&log_every=3"}),
+        ("dataset + graph=auto, batch 32", {"file": "builtin://resnet50?batch=32&steps=80&graph=auto&log_every=20", "data": data}),
+        ("hipGraph + checkpoint every 20", {"file": "builtin://resnet50?batch=32&steps=60&graph=1&ckpt_every=20&log_every=20",
+                                            "export": export + "-g"}),
+        ("resume of it, graph=auto", {"file": "builtin://resnet50?batch=32&steps=120&graph=auto&resume=1&log_every=20",
+                                      "export": export + "-g"}),
+        ("same 120 steps without graph or resume", {"file": "builtin://resnet50?batch=32&steps=120&log_every=20"}),
+        ("wide_deep + graph=auto", {"file": "builtin://wide_deep?batch=8192&steps=80&graph=auto&log_every=20"}),
+        ("inception_v3 + hipGraph", {"file": "builtin://inception_v3?batch=16&steps=20&graph=1&log_every=10"}),
+    ]
+    if len(sys.argv) > 2:
+        jobs = jobs[-int(sys.argv[2]):]
+if len(sys.argv) > 1 and sys.argv[1] == "resume":
+    # interrupted + resumed == uninterrupted, eagerly and replayed (batch 64: the smallest size whose step is reproducible
+    # run to run in the default mode); and the graph trial against the eager loop for Wide&Deep
+    R6 = "builtin://resnet50?batch=64&log_every=20&"
+    W8 = "builtin://wide_deep?batch=8192&log_every=20&"
+    jobs = [
+        ("60 steps, eager", {"file": R6 + "steps=60"}),
+        ("30 steps + checkpoint, eager", {"file": R6 + "steps=30", "export": export + "-e"}),
+        ("resumed to 60, eager", {"file": R6 + "steps=60&resume=1", "export": export + "-e"}),
+        ("60 steps, hipGraph", {"file": R6 + "steps=60&graph=1"}),
+        ("30 steps + checkpoint, hipGraph", {"file": R6 + "steps=30&graph=1", "export": export + "-h"}),
+        ("resumed to 60, hipGraph", {"file": R6 + "steps=60&resume=1&graph=1", "export": export + "-h"}),
+        ("wide_deep 80 steps, eager", {"file": W8 + "steps=80"}),
+        ("wide_deep 80 steps, hipGraph", {"file": W8 + "steps=80&graph=1"}),
+        ("wide_deep 80 steps, graph=auto", {"file": W8 + "steps=80&graph=auto"}),
     ]
 if len(sys.argv) > 1 and sys.argv[1] == "edges":
     # control-plane edges on the real device: two jobs at once on one GPU, a cancel mid-run, a deadline, an unsatisfiable gang
@@ -220,18 +246,25 @@ for name, spec in jobs:
     for f in sorted(os.listdir(logs)):
         if uid in f and "worker" in f:
             log = open(os.path.join(logs, f), errors="replace").read()
-    notes = [k for k in ("resumed from step", "captured in a hipGraph", "input:", "wrote checkpoint", "injecting", "steps on cuda") if k in log]
+    notes = [k for k in ("resumed from step", "captured in a hipGraph", "input:", "wrote checkpoint", "injecting", "steps on cuda",
+                         "-> replaying", "-> staying eager", "ignored") if k in log]
     rcl = rec.get("hbm_reclaim") or []
     row = {"job": name, "status": rec.get("status"), "reason": rec.get("reason"), "step": m.get("step"),
            "first_loss": m.get("first_loss"), "final_loss": m.get("final_loss"), "items_per_sec": m.get("items_per_sec"),
            "seconds": round(time.time() - t0, 1), "log_notes": notes,
            "hbm_reclaimed": [r.get("reclaimed") for r in rcl]}
     out.append(row)
+    def g4(v):
+        try:
+            return "%.4g" % float(v)        # (cutting the string cut the exponent off: 7.04e-06 read as 7.04)
+        except (TypeError, ValueError):
+            return str(v)
+
     print("%-30s %-10s step %-4s loss %s -> %s  %s  reclaimed %s  %.1f s %s" % (
-        name, row["status"], row["step"], str(row["first_loss"])[:6], str(row["final_loss"])[:6], notes, row["hbm_reclaimed"],
+        name, row["status"], row["step"], g4(row["first_loss"]), g4(row["final_loss"]), notes, row["hbm_reclaimed"],
         row["seconds"], ("(" + str(row["reason"]) + ")") if row["reason"] else ""), flush=True)
 aio.stop()
-odd = len(sys.argv) > 1 and sys.argv[1] == "odd"
+odd = len(sys.argv) > 1 and sys.argv[1] in ("odd", "resume")
 json.dump(out, open(os.path.join("gpurun_out", "rest_matrix_odd.json" if odd else "rest_matrix.json"), "w"), indent=1)
 if odd:
     bad = [r["job"] for r in out if "HUNG" in str(r["status"]) or (r["status"] != "succeeded" and not r["reason"])]
