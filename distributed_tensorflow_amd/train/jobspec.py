@@ -41,9 +41,11 @@ class TrainOptions:
     seed: int = 1234
     log_every: int = 10
     fault: str = ""                 # e.g. "exit:worker=1,step=3,code=17" / "hang:worker=0,step=2"
-    graph: object = False           # 1: capture the whole training step in one hipGraph after 3 eager steps; "auto": capture,
+    graph: object = "default"       # 1: capture the whole training step in one hipGraph after 3 eager steps; "auto": capture,
                                     # then time eager steps against replays and keep the faster (small batches are
-                                    # host-bound eagerly: ResNet-50 batch 32 runs 1.8x faster replayed, batch 256 does not)
+                                    # host-bound eagerly: ResNet-50 batch 32 runs 2.1x faster replayed, batch 256 does not);
+                                    # 0: never.  "default" = auto for a one-worker GPU job (measured on one device), 0 for
+                                    # jobs of several workers (a capture with live collectives is not measured there yet)
     gemm_tuning: str = "auto"       # shipped per-shape GEMM choices: on | off | auto (on from 10 000 steps: reading them
                                     # costs 1-1.5 s before the first step and returns 1-1.5 % per step)
     input: str = "auto"             # auto: the job's `data` directory if it holds a dataset (train/data.py) | synthetic
@@ -61,8 +63,8 @@ def _coerce(key, val):
         return int(val)
     if key in _FLOAT:
         return float(val)
-    if key == "graph" and str(val).lower() == "auto":
-        return "auto"
+    if key == "graph" and str(val).lower() in ("auto", "default"):
+        return str(val).lower()
     if key in _BOOL:
         return str(val).lower() in ("1", "true", "yes", "on")
     return val

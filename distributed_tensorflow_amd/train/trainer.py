@@ -178,6 +178,9 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
     TRIAL = (("graph", 3, False), ("graph", 8, True), ("graph", 8, True))
     PRE = 3 + (8 if graph == "auto" else 0)       # eager steps before the capture; in auto mode the last 8 are timed
     pre_t0, eager_ms = None, None
+    if graph == "auto" and steps < PRE + sum(n for _, n, _ in TRIAL) + 8:
+        graph, static_input = False, False          # no room for a trial: a capture (0.6 s) would be a guess, stay eager
+        cur["b"] = batch
     # the eager steps before a capture run on a side stream (the protocol torch.cuda.graph documents and bench.py follows):
     # captured after warm-up steps on the DEFAULT stream, hipStreamEndCapture crashed the process on ROCm 7.2
     warm = None
@@ -508,6 +511,9 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
     remaining = max(0, opts.steps - start_step)
     items = opts.batch * num_workers
     use_graph = opts.graph
+    if use_graph == "default":
+        use_graph = "auto" if (num_workers == 1 and device.type == "cuda" and placement != "dedicated" and not one_sided
+                               and getattr(ps, "update_mode", "") != "stale") else False
     if use_graph:
         # a captured step replays ONE fixed sequence of kernels: a stale pipeline rotates through `staleness` staging
         # slots and waits for events of earlier steps, the one-sided and dedicated runtimes talk to other processes from
