@@ -209,7 +209,9 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
                 # the eager step is timed BEFORE the capture: afterwards it measured 2-5 ms per step slower than in a
                 # process that never captured (scripts/train_loop_auto_probe.py), which would bias the choice
                 eager_ms = (time.perf_counter() - pre_t0) / (PRE - 3)
-            time.sleep(0.5)             # the RCCL watchdog retires the earlier collectives (no event queries mid-capture)
+            live = getattr(getattr(ps, "comm", None), "live", False)
+            if live:
+                time.sleep(0.5)         # the RCCL watchdog retires the earlier collectives (no event queries mid-capture)
             if hasattr(ps, "disable_prefetch"):
                 ps.disable_prefetch()
             step_before = ps.global_step

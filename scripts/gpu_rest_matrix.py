@@ -78,6 +78,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "odd":
     ]
     if len(sys.argv) > 2:
         jobs = jobs[-int(sys.argv[2]):]
+if len(sys.argv) > 1 and sys.argv[1] == "cost":
+    # what does the default (graph=auto for a one-worker GPU job) cost or gain a job, start to end?  items/s of the whole loop
+    B = "builtin://resnet50?log_every=50&"
+    jobs = [(("batch %d, %d steps, graph=%s" % (b, n, g)), {"file": B + "batch=%d&steps=%d&graph=%s" % (b, n, g)})
+            for b, n in ((256, 60), (256, 300), (64, 300), (32, 300)) for g in ("0", "default")]
 if len(sys.argv) > 1 and sys.argv[1] == "resume":
     # interrupted + resumed == uninterrupted, eagerly and replayed (batch 64: the smallest size whose step is reproducible
     # run to run in the default mode); and the graph trial against the eager loop for Wide&Deep
@@ -260,11 +265,13 @@ for name, spec in jobs:
         except (TypeError, ValueError):
             return str(v)
 
+    if len(sys.argv) > 1 and sys.argv[1] == "cost":
+        print("%-38s %8.0f items/s over the whole loop" % (name, float(row["items_per_sec"] or 0)), flush=True)
     print("%-30s %-10s step %-4s loss %s -> %s  %s  reclaimed %s  %.1f s %s" % (
         name, row["status"], row["step"], g4(row["first_loss"]), g4(row["final_loss"]), notes, row["hbm_reclaimed"],
         row["seconds"], ("(" + str(row["reason"]) + ")") if row["reason"] else ""), flush=True)
 aio.stop()
-odd = len(sys.argv) > 1 and sys.argv[1] in ("odd", "resume")
+odd = len(sys.argv) > 1 and sys.argv[1] in ("odd", "resume", "cost")
 json.dump(out, open(os.path.join("gpurun_out", "rest_matrix_odd.json" if odd else "rest_matrix.json"), "w"), indent=1)
 if odd:
     bad = [r["job"] for r in out if "HUNG" in str(r["status"]) or (r["status"] != "succeeded" and not r["reason"])]
