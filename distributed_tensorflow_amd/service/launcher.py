@@ -402,6 +402,7 @@ class LocalCluster:
             gpus = list(range(min(n, cap))) if n else []
         self._free_gpus = list(gpus)
         self._all_gpus = list(gpus)
+        self._gang_fifo = cfg.getboolean("launcher", "gang_fifo", True)
         self._gangs = {}            # job uid -> devices set aside for its tasks that have not started yet
         self._gang_broken = set()   # jobs being torn down: no reservation any more
         self._log_dir = log_dir or cfg.get("launcher", "log_dir", "logs/tasks")
@@ -601,10 +602,13 @@ class LocalCluster:
 
     def _schedule(self):
         # caller holds the lock; start every pending task that fits (FIFO)
+        waiting = False     # an earlier job is waiting for ALL its devices: later jobs do not take devices past it
         for t in list(self._jobs.values()):
             if t.proc is not None or t.deleted or t.status["phase"] != "Pending":
                 continue
             need = t.requested_gpus if self._all_gpus else 0
+            if waiting and self._gang_fifo and (need > 0 or (t.gang and t.gang_gpus > 0)) and t.gang not in self._gangs:
+                continue
             pool = self._free_gpus
             if t.gang and t.gang_gpus > 0 and self._all_gpus and t.gang not in self._gang_broken:
                 # all-or-nothing per job: the first task that finds the WHOLE job's devices free sets them aside, the
@@ -613,6 +617,9 @@ class LocalCluster:
                 # can therefore never hold half of the node each and wait for the other half.
                 if t.gang not in self._gangs:
                     if t.gang_gpus > len(self._free_gpus):
+                        # no back-filling past a waiting job: with it, a stream of small jobs keeps the devices busy and
+                        # a job that needs the whole node never finds them all free
+                        waiting = True
                         continue
                     if self._hot is not None:
                         self._free_gpus.sort(key=lambda g: (not self._hot.is_ready(g), g))

@@ -594,3 +594,29 @@ def test_package_front_door_lists_and_dispatches_commands(capsys):
     assert all(w in out for w in ("serve", "cleaner | reaper", "job submit", "inspect", "evaluate", "build"))
     assert front.main(["nope"]) == 2 and "unknown command 'nope'" in capsys.readouterr().err
     assert front.main(["inspect", "/nonexistent-export"]) == 1 and "no checkpoint under" in capsys.readouterr().err
+
+
+def test_small_jobs_do_not_overtake_a_job_that_waits_for_the_whole_node(cluster3):
+    """No back-filling past a waiting gang: a 1-GPU job runs, a 3-GPU job waits for all three devices, and the 1-GPU jobs
+    submitted after it stay Pending although two devices are free -- otherwise a steady stream of them would starve it.
+    When the first job ends the big one gets the node, and the small ones follow."""
+    c = cluster3
+    first = c.create_namespaced_job("default", _gang("aaaaaaaa-1111-11f1-8000-000000000001", 1, file_field="sleep:1.0")[0])
+    big = [c.create_namespaced_job("default", b) for b in _gang("bbbbbbbb-2222-11f1-8000-000000000002", 3, file_field="sleep:0.3")]
+    small = [c.create_namespaced_job("default", _gang("cccccccc-3333-11f1-8000-00000000000%d" % i, 1, file_field="sleep:0.2")[0])
+             for i in range(2)]
+    assert first["status"]["phase"] == "Running" and c.free_gpus() == [1, 2]
+    assert all(j["status"]["phase"] == "Pending" for j in big + small)
+    names = [j["metadata"]["name"] for j in big + small]
+    done = {}
+
+    def finished():
+        for n in names:
+            st = c.read_namespaced_job(n, "default")["status"]
+            if st["succeeded"] == 1 and n not in done:
+                done[n] = st["startTime"]
+        return len(done) == len(names)
+
+    assert _wait(finished, 30), done
+    assert max(done[n] for n in names[:3]) <= min(done[n] for n in names[3:])       # the big job started first
+    assert _wait(lambda: c.free_gpus() == [0, 1, 2], 10)
