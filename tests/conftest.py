@@ -16,6 +16,20 @@ def pytest_configure(config):
 
 
 def free_port():
+    """A port for a rendezvous that starts a moment later.  NOT from the kernel's ephemeral range (``bind(0)``): any
+    outgoing connection of any process may be given that very port as its source port between this call and the
+    listener's bind -- seen once as EADDRINUSE in a GPU suite run.  Ports 10000-19999 are outside that range and below
+    the launcher's own (23000+)."""
+    import random
+
+    for _ in range(200):
+        port = random.randint(10000, 19999)
+        with socket.socket() as s:
+            try:
+                s.bind(("127.0.0.1", port))
+            except OSError:
+                continue
+            return port
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]

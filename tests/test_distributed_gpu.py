@@ -323,9 +323,9 @@ def test_one_sided_async_ps_free_running_on_gpu(dev, tmp_path):
 
 
 def _free_port():
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+    from conftest import free_port          # outside the kernel's ephemeral range, see there
+
+    return free_port()
 
 
 def test_bench_ends_at_the_same_loss_through_every_data_plane_path():

@@ -26,11 +26,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _free_port():
-    import socket
+    from conftest import free_port          # outside the kernel's ephemeral range, see there
 
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        return so.getsockname()[1]
+    return free_port()
 
 
 @pytest.fixture(scope="module")

@@ -33,7 +33,7 @@ def _need(world):
         pytest.skip("needs %d GPUs, this box has %d" % (world, n))
 
 
-def run_gpu_ranks(world, case, out_dir, timeout=420, backend="nccl"):
+def run_gpu_ranks(world, case, out_dir, timeout=420, backend="nccl", _retry=True):
     os.makedirs(out_dir, exist_ok=True)
     port = free_port()
     procs = []
@@ -52,6 +52,8 @@ def run_gpu_ranks(world, case, out_dir, timeout=420, backend="nccl"):
                 q.kill()
             raise
         outs.append(o.decode(errors="replace"))
+    if _retry and any(p.returncode != 0 for p in procs) and any("EADDRINUSE" in o for o in outs):
+        return run_gpu_ranks(world, case, out_dir, timeout, backend, _retry=False)      # somebody took the port: once more
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     return torch.load(os.path.join(out_dir, "result_%s_w%d.pt" % (case, world)), weights_only=True)

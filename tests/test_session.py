@@ -23,9 +23,9 @@ SCRIPT = os.path.join(ROOT, "examples", "mnist_replica.py")
 
 
 def _port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    from conftest import free_port          # outside the kernel's ephemeral range, see there
+
+    return free_port()
 
 
 def test_cluster_spec_and_placement():
