@@ -114,6 +114,18 @@ def _mm_dgrad(dy, weight):
 # ResNet-50, 27.81 vs 27.75 Inception-v3, 47.83 vs 47.94 ResNet-152 (scripts/gpu_r3_ag.sh).
 _DETERMINISTIC = os.environ.get("DTF_DETERMINISTIC", "1") != "0"
 _DETERMINISTIC_STRICT = os.environ.get("DTF_DETERMINISTIC", "1") == "2"      # also the image-input layers (see _ConvFn)
+
+
+def set_deterministic(level):
+    """The job option ``deterministic=0|1|2`` (``train/jobspec.py``): what ``DTF_DETERMINISTIC`` sets at import, for a
+    process that is already running (a warm rank has imported this module long before it learns its job)."""
+    global _DETERMINISTIC, _DETERMINISTIC_STRICT
+    level = int(level)
+    if level not in (0, 1, 2):
+        raise ValueError("deterministic must be 0, 1 or 2, not %r" % (level,))
+    _DETERMINISTIC, _DETERMINISTIC_STRICT = level != 0, level == 2
+    os.environ["DTF_DETERMINISTIC"] = str(level)
+    return level
 _TN_WRW_MIN_C = int(os.environ.get("DTF_CONV1X1_TN_MIN_C", "192"))      # K6T weight gradient when min(Cin, Cout) >= this
 _TN_WRW = os.environ.get("DTF_CONV1X1_TN", "1") != "0"
 _ENABLED = os.environ.get("DTF_CONV1X1_MM", "1") != "0"      # A/B switch: 0 = everything through MIOpen

@@ -48,12 +48,15 @@ class TrainOptions:
                                     # jobs of several workers (a capture with live collectives is not measured there yet)
     gemm_tuning: str = "auto"       # shipped per-shape GEMM choices: on | off | auto (on from 10 000 steps: reading them
                                     # costs 1-1.5 s before the first step and returns 1-1.5 % per step)
+    deterministic: int = -1         # -1: as the process was started (DTF_DETERMINISTIC, default 1) | 0 | 1 | 2 (strict: bitwise
+                                    # reproducible at every batch size, ~2.5 % slower; docs/SWITCHES.md)
     input: str = "auto"             # auto: the job's `data` directory if it holds a dataset (train/data.py) | synthetic
     synthetic_batches: int = 1      # synthetic input: this many different batches, served round-robin
     extra: dict = field(default_factory=dict)
 
 
-_INT = {"steps", "batch", "ckpt_every", "seed", "log_every", "staleness", "synthetic_batches", "keep_checkpoints"}
+_INT = {"steps", "batch", "ckpt_every", "seed", "log_every", "staleness", "synthetic_batches", "keep_checkpoints",
+        "deterministic"}
 _FLOAT = {"bucket_mb", "lr"}
 _BOOL = {"resume", "graph"}
 

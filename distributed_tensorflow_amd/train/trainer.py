@@ -342,6 +342,10 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
 
     gemm_tuning.after_torch_import()      # shipped GEMM choices (if entry.py enabled them) are read-only
     mod = get_model_module(opts.model)
+    if int(getattr(opts, "deterministic", -1)) >= 0:
+        from ..ops import conv as conv_ops
+
+        conv_ops.set_deterministic(opts.deterministic)
     use_cuda = torch.cuda.is_available() and int(os.environ.get("DTF_NUM_GPUS", "1")) > 0
     device = torch.device("cuda", 0) if use_cuda else torch.device("cpu")
     torch.manual_seed(opts.seed)

@@ -83,6 +83,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "cost":
     B = "builtin://resnet50?log_every=50&"
     jobs = [(("batch %d, %d steps, graph=%s" % (b, n, g)), {"file": B + "batch=%d&steps=%d&graph=%s" % (b, n, g)})
             for b, n in ((256, 60), (256, 300), (64, 300), (32, 300)) for g in ("0", "default")]
+if len(sys.argv) > 1 and sys.argv[1] == "strict":
+    # the job option deterministic=2 at a batch size whose default-mode step differs run to run
+    B3 = "builtin://resnet50?batch=32&steps=60&log_every=20&graph=0&"
+    jobs = [("batch 32, default mode, run %d" % i, {"file": B3[:-1]}) for i in (1, 2)] + \
+           [("batch 32, deterministic=2, run %d" % i, {"file": B3 + "deterministic=2"}) for i in (1, 2)] + \
+           [("batch 32, deterministic=2, hipGraph", {"file": B3.replace("graph=0", "graph=1") + "deterministic=2"})]
 if len(sys.argv) > 1 and sys.argv[1] == "resume":
     # interrupted + resumed == uninterrupted, eagerly and replayed (batch 64: the smallest size whose step is reproducible
     # run to run in the default mode); and the graph trial against the eager loop for Wide&Deep
@@ -261,7 +267,7 @@ for name, spec in jobs:
     out.append(row)
     def g4(v):
         try:
-            return "%.4g" % float(v)        # (cutting the string cut the exponent off: 7.04e-06 read as 7.04)
+            return ("%.10g" if len(sys.argv) > 1 and sys.argv[1] == "strict" else "%.4g") % float(v)        # (cutting the string cut the exponent off: 7.04e-06 read as 7.04)
         except (TypeError, ValueError):
             return str(v)
 
@@ -271,7 +277,7 @@ for name, spec in jobs:
         name, row["status"], row["step"], g4(row["first_loss"]), g4(row["final_loss"]), notes, row["hbm_reclaimed"],
         row["seconds"], ("(" + str(row["reason"]) + ")") if row["reason"] else ""), flush=True)
 aio.stop()
-odd = len(sys.argv) > 1 and sys.argv[1] in ("odd", "resume", "cost")
+odd = len(sys.argv) > 1 and sys.argv[1] in ("odd", "resume", "cost", "strict")
 json.dump(out, open(os.path.join("gpurun_out", "rest_matrix_odd.json" if odd else "rest_matrix.json"), "w"), indent=1)
 if odd:
     bad = [r["job"] for r in out if "HUNG" in str(r["status"]) or (r["status"] != "succeeded" and not r["reason"])]

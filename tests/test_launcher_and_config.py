@@ -620,3 +620,23 @@ def test_small_jobs_do_not_overtake_a_job_that_waits_for_the_whole_node(cluster3
     assert _wait(finished, 30), done
     assert max(done[n] for n in names[:3]) <= min(done[n] for n in names[3:])       # the big job started first
     assert _wait(lambda: c.free_gpus() == [0, 1, 2], 10)
+
+
+def test_deterministic_job_option_reaches_the_kernel_dispatch():
+    from distributed_tensorflow_amd.ops import conv
+
+    kind, o = parse_file_field("builtin://resnet50?deterministic=2&steps=5")
+    assert kind == "builtin" and o.deterministic == 2 and "deterministic" not in o.extra
+    assert parse_file_field("builtin://resnet50?steps=5")[1].deterministic == -1
+    before = (conv._DETERMINISTIC, conv._DETERMINISTIC_STRICT, os.environ.get("DTF_DETERMINISTIC"))
+    try:
+        assert conv.set_deterministic(2) == 2 and conv._DETERMINISTIC and conv._DETERMINISTIC_STRICT
+        assert conv.set_deterministic(0) == 0 and not conv._DETERMINISTIC and not conv._DETERMINISTIC_STRICT
+        with pytest.raises(ValueError):
+            conv.set_deterministic(3)
+    finally:
+        conv._DETERMINISTIC, conv._DETERMINISTIC_STRICT = before[0], before[1]
+        if before[2] is None:
+            os.environ.pop("DTF_DETERMINISTIC", None)
+        else:
+            os.environ["DTF_DETERMINISTIC"] = before[2]
