@@ -34,6 +34,12 @@ class TrainOptions:
     wire_dtype: str = "auto"        # auto | bf16 | fp32
     push: str = "reduce_scatter"    # reduce_scatter | all_to_all
     lr: float = -1.0                # <0: model default
+    lr_warmup_steps: int = 0        # linear warm-up of the learning rate over the first N steps of the JOB (a resumed job continues it)
+    lr_schedule: str = "constant"   # after the warm-up: constant | cosine (to lr_final_fraction * lr at the last step) |
+                                    # piecewise (lr *= lr_decay_factor at each of lr_boundaries, fractions of `steps`)
+    lr_boundaries: str = "0.5,0.75"
+    lr_decay_factor: float = 0.1
+    lr_final_fraction: float = 0.0
     optimizer: str = ""             # "": model default
     ckpt_every: int = 0             # 0: only at the end (when export is set)
     keep_checkpoints: int = 5       # complete checkpoints kept in `export` (TF1 Saver's max_to_keep); 0: all
@@ -56,8 +62,8 @@ class TrainOptions:
 
 
 _INT = {"steps", "batch", "ckpt_every", "seed", "log_every", "staleness", "synthetic_batches", "keep_checkpoints",
-        "deterministic"}
-_FLOAT = {"bucket_mb", "lr"}
+        "deterministic", "lr_warmup_steps"}
+_FLOAT = {"bucket_mb", "lr", "lr_decay_factor", "lr_final_fraction"}
 _BOOL = {"resume", "graph"}
 
 

@@ -134,8 +134,38 @@ def restore_checkpoint(model, ps, export, tf_names, step=None):
     return rd.step
 
 
+def lr_schedule(opts, base_lr, total_steps):
+    """``step (0-based, of the whole job) -> learning rate`` from the job options ``lr_warmup_steps``, ``lr_schedule``,
+    ``lr_boundaries``, ``lr_decay_factor``, ``lr_final_fraction``; ``None`` when the rate is constant.  What
+    tf_cnn_benchmarks-style scripts do with ``tf.train.piecewise_constant`` / a warm-up ramp."""
+    import math
+
+    warm = max(0, int(getattr(opts, "lr_warmup_steps", 0) or 0))
+    kind = str(getattr(opts, "lr_schedule", "constant") or "constant").lower()
+    if kind not in ("constant", "cosine", "piecewise"):
+        raise ValueError("lr_schedule must be constant, cosine or piecewise, not %r" % kind)
+    if warm == 0 and kind == "constant":
+        return None
+    total = max(1, int(total_steps))
+    bounds = sorted(float(b) for b in str(getattr(opts, "lr_boundaries", "") or "").split(",") if b.strip())
+    factor = float(getattr(opts, "lr_decay_factor", 0.1))
+    final = float(getattr(opts, "lr_final_fraction", 0.0))
+
+    def at(step):
+        if step < warm:
+            return base_lr * (step + 1) / warm
+        if kind == "cosine":
+            x = min(1.0, (step - warm) / max(1, total - 1 - warm))
+            return base_lr * (final + (1.0 - final) * 0.5 * (1.0 + math.cos(math.pi * x)))
+        if kind == "piecewise":
+            return base_lr * factor ** sum(1 for b in bounds if step >= b * total)
+        return base_lr
+
+    return at
+
+
 def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=None, on_step=None,
-               items_per_step=None, start_step=0, graph=False, batches=None, on_log=None):
+               items_per_step=None, start_step=0, graph=False, batches=None, on_log=None, lr_fn=None):
     """Runs ``steps`` PS steps; returns (last_loss, seconds, steps_done).  ``graph=True``: after three eager steps
     the whole step (forward, backward, hook-launched PS pipeline incl. its collectives) is captured in one hipGraph
     and replayed -- the ~600 launches of a step then cost the host one call (GPU only).  ``graph="auto"``: capture, then
@@ -189,6 +219,8 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
         warm.wait_stream(torch.cuda.current_stream(dev))
     for it in range(start_step, start_step + steps):
         _inject(fault, worker, it + 1)
+        if lr_fn is not None:
+            ps.set_lr(lr_fn(it))        # a device-side scalar the applies read: also valid for a replayed step
         warming = warm is not None and replay is None and graph and it - start_step < PRE
         if warming:
             if graph == "auto" and it - start_step == 3:
@@ -541,7 +573,8 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
     try:
         last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
                                    fault=fault, on_step=on_step, items_per_step=items, start_step=start_step,
-                                   graph=use_graph, batches=batches, on_log=on_log)
+                                   graph=use_graph, batches=batches, on_log=on_log,
+                                   lr_fn=lr_schedule(opts, float(ps.lr), opts.steps) if (hasattr(ps, "set_lr") and hasattr(ps, "lr")) else None)
     finally:
         if batches is not None:
             batches.close()

@@ -89,6 +89,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "strict":
     jobs = [("batch 32, default mode, run %d" % i, {"file": B3[:-1]}) for i in (1, 2)] + \
            [("batch 32, deterministic=2, run %d" % i, {"file": B3 + "deterministic=2"}) for i in (1, 2)] + \
            [("batch 32, deterministic=2, hipGraph", {"file": B3.replace("graph=0", "graph=1") + "deterministic=2"})]
+if len(sys.argv) > 1 and sys.argv[1] == "lr":
+    # learning-rate schedule (warm-up + cosine) eagerly, replayed, and interrupted + resumed: one final loss
+    L = "builtin://resnet50?batch=64&log_every=20&lr_warmup_steps=10&lr_schedule=cosine&lr_final_fraction=0.05&"
+    jobs = [
+        ("constant lr, 60 steps", {"file": "builtin://resnet50?batch=64&log_every=20&steps=60&graph=0"}),
+        ("warm-up + cosine, eager", {"file": L + "steps=60&graph=0"}),
+        ("warm-up + cosine, hipGraph", {"file": L + "steps=60&graph=1"}),
+        ("warm-up + cosine, 30 steps of 60 + checkpoint", {"file": L + "steps=60&graph=0&fault=exit:worker=0,step=31,code=9&ckpt_every=30",
+                                                           "export": export + "-lr"}),
+        ("resumed to 60 (default graph=auto)", {"file": L + "steps=60&resume=1", "export": export + "-lr"}),
+    ]
 if len(sys.argv) > 1 and sys.argv[1] == "resume":
     # interrupted + resumed == uninterrupted, eagerly and replayed (batch 64: the smallest size whose step is reproducible
     # run to run in the default mode); and the graph trial against the eager loop for Wide&Deep
@@ -267,7 +278,7 @@ for name, spec in jobs:
     out.append(row)
     def g4(v):
         try:
-            return ("%.10g" if len(sys.argv) > 1 and sys.argv[1] == "strict" else "%.4g") % float(v)        # (cutting the string cut the exponent off: 7.04e-06 read as 7.04)
+            return ("%.10g" if len(sys.argv) > 1 and sys.argv[1] in ("strict", "lr") else "%.4g") % float(v)        # (cutting the string cut the exponent off: 7.04e-06 read as 7.04)
         except (TypeError, ValueError):
             return str(v)
 
@@ -277,7 +288,7 @@ for name, spec in jobs:
         name, row["status"], row["step"], g4(row["first_loss"]), g4(row["final_loss"]), notes, row["hbm_reclaimed"],
         row["seconds"], ("(" + str(row["reason"]) + ")") if row["reason"] else ""), flush=True)
 aio.stop()
-odd = len(sys.argv) > 1 and sys.argv[1] in ("odd", "resume", "cost", "strict")
+odd = len(sys.argv) > 1 and sys.argv[1] in ("odd", "resume", "cost", "strict", "lr")
 json.dump(out, open(os.path.join("gpurun_out", "rest_matrix_odd.json" if odd else "rest_matrix.json"), "w"), indent=1)
 if odd:
     bad = [r["job"] for r in out if "HUNG" in str(r["status"]) or (r["status"] != "succeeded" and not r["reason"])]

@@ -417,3 +417,47 @@ def test_graph_auto_times_eager_against_replay_and_keeps_the_faster(margin, expe
     out = capsys.readouterr().out
     assert "hipGraph trial: eager" in out and expect in out, out
     assert torch.equal(ends[0], ends[1])
+
+
+def test_learning_rate_schedule_options_and_their_use_in_the_training_loop():
+    """``lr_warmup_steps`` / ``lr_schedule=cosine|piecewise`` (job options): the values, and that ``train_loop`` hands the
+    rate of the JOB's step to the PS runtime -- a run resumed at step 6 continues the schedule instead of restarting it."""
+    import types
+
+    from distributed_tensorflow_amd.models import get_model_module
+    from distributed_tensorflow_amd.parallel.comm import Comm
+    from distributed_tensorflow_amd.parallel.ps_runtime import OptimizerSpec, ShardedPS
+    from distributed_tensorflow_amd.train.jobspec import parse_file_field
+    from distributed_tensorflow_amd.train.trainer import lr_schedule, train_loop
+
+    _, o = parse_file_field("builtin://mnist_mlp?lr_warmup_steps=4&lr_schedule=piecewise&lr_boundaries=0.5,0.75&lr_decay_factor=0.1")
+    f = lr_schedule(o, 0.8, 20)
+    assert [round(f(t), 6) for t in (0, 1, 3, 4, 9, 10, 14, 15, 19)] == [0.2, 0.4, 0.8, 0.8, 0.8, 0.08, 0.08, 0.008, 0.008]
+    _, o = parse_file_field("builtin://mnist_mlp?lr_warmup_steps=2&lr_schedule=cosine&lr_final_fraction=0.1")
+    f = lr_schedule(o, 1.0, 12)
+    assert f(0) == 0.5 and f(1) == 1.0 and f(2) == 1.0 and abs(f(11) - 0.1) < 1e-12 and f(6) < f(4) < f(2)
+    assert lr_schedule(parse_file_field("builtin://mnist_mlp")[1], 0.1, 10) is None
+    with pytest.raises(ValueError):
+        lr_schedule(types.SimpleNamespace(lr_schedule="exponential"), 0.1, 10)
+
+    mod = get_model_module("mnist_mlp")
+    seen = []
+
+    def run(start, n):
+        torch.manual_seed(0)
+        model = mod.build()
+        ps = ShardedPS(list(model.named_parameters()), Comm.single(), OptimizerSpec(kind="sgd", lr=1.0))
+        orig = ps.step
+
+        def step():
+            seen.append(round(ps.lr, 6))
+            return orig()
+
+        ps.step = step
+        train_loop(model, mod, ps, mod.synthetic_batch(16, device="cpu", seed=1), n, log_every=0, start_step=start, lr_fn=f)
+
+    run(0, 12)
+    whole = list(seen)
+    del seen[:]
+    run(6, 6)
+    assert whole == [round(f(t), 6) for t in range(12)] and seen == whole[6:]
