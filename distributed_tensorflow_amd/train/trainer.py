@@ -569,7 +569,8 @@ def _run_task(job_name, task_index, num_ps, num_workers, placement, opts, data_d
 
         # the training curve: <export>/scalars.jsonl + a thinned copy in the job's metrics (train/summary.py)
         curve = ScalarLog(export if do_ckpt else None, sink=metrics)
-        on_log = lambda step, loss, rate: curve.add(step, loss=loss, items_per_sec=rate)      # noqa: E731
+        on_log = lambda step, loss, rate: curve.add(step, loss=loss, items_per_sec=rate,      # noqa: E731
+                                                    **({"lr": ps.lr} if hasattr(ps, "lr") else {}))
     try:
         last, secs, n = train_loop(model, mod, ps, batch, remaining, worker=task_index, log_every=opts.log_every,
                                    fault=fault, on_step=on_step, items_per_step=items, start_step=start_step,
