@@ -221,6 +221,11 @@ def train_loop(model, mod, ps, batch, steps, *, worker=0, log_every=10, fault=No
         _inject(fault, worker, it + 1)
         if lr_fn is not None:
             ps.set_lr(lr_fn(it))        # a device-side scalar the applies read: also valid for a replayed step
+            if replay is not None and getattr(ps, "comm_stream", None) is not None:
+                # the fill runs on the comm stream, after everything launched so far (the previous replay included); the
+                # replay launched next must in turn come after the fill -- eagerly the pull events order that, a replayed
+                # graph knows nothing of the real comm stream
+                torch.cuda.current_stream(dev).wait_stream(ps.comm_stream)
         warming = warm is not None and replay is None and graph and it - start_step < PRE
         if warming:
             if graph == "auto" and it - start_step == 3:
