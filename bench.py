@@ -218,6 +218,9 @@ def main():
 
             def graph_step():
                 next_lr()
+                if a.lr_warmup_steps > 0 and getattr(ps, "comm_stream", None) is not None:
+                    # the rate is filled on the comm stream (after everything launched so far); the replay comes after it
+                    torch.cuda.current_stream().wait_stream(ps.comm_stream)
                 graph.replay()
                 return static_loss
 
